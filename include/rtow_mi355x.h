@@ -1,0 +1,246 @@
+/*
+ * rtow_mi355x.h — C-ABI of the MI355X (gfx950) wavefront path tracer.
+ *
+ * This is the drop-in boundary for the per-pixel integration loop of
+ * zhouhang95/ray_tracing_in_one_weekend.  The reference has no FFI of its own: the seam is
+ * the pair (scene builder -> renderer) described in SURVEY.md §8(b).  Every entry point
+ * below names the reference interface it replaces (paths relative to /root/reference).
+ *
+ *   scene side : demo_scene.rs:37,229  fn(aspect_ratio) -> (Vec<Arc<dyn Hitable>>, Camera)
+ *                lib.rs:11             SKY_COLOR (global sky fn pointer)
+ *   render side: main.rs:77-108        the per-column pixel loop
+ *                main.rs:38-60         ray_color (closest hit -> emitted/scatter -> recurse)
+ *   output     : main.rs:98-105,127    /spp, gamma 2, *255.99 as u8, vertical flip
+ *
+ * Conventions
+ *   - plain C structs, pointers and sizes; no C++/torch types; no exceptions cross it.
+ *   - every function returns 0 on success, a negative RT_ERR_* otherwise; text via
+ *     rt_last_error().
+ *   - the caller owns all buffers; rt_scene_upload() copies and retains nothing host-side.
+ *   - a context is bound to ONE GPU and is driven by one host thread (one process per
+ *     GPU; multi-GPU sharding is expressed through RtParams.shard_*).
+ *   - fp32 throughout; image row 0 is the BOTTOM row in the f32 output (reference `j`
+ *     order, main.rs:84) and the TOP row in the RGB8 output (after the flip, main.rs:127).
+ */
+#ifndef RTOW_MI355X_H
+#define RTOW_MI355X_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+/* error codes */
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)   /* bad argument / inconsistent scene            */
+#define RT_ERR_DEVICE (-2)    /* HIP runtime error (text in rt_last_error)   */
+#define RT_ERR_NOMEM (-3)     /* host or device allocation failed            */
+#define RT_ERR_UNSUPPORTED (-4)
+#define RT_ERR_STATE (-5)     /* e.g. render before scene upload             */
+
+/* Material tags.  Order follows SURVEY.md §3.4; one tag per `impl Material`. */
+enum RtMatType {
+    RT_MAT_EMISSION = 0,         /* material.rs:17-29   tex0 = emit                          */
+    RT_MAT_DIFFUSE = 1,          /* material.rs:31-46   tex0 = albedo                        */
+    RT_MAT_LAMBERT = 2,          /* material.rs:48-59   tex0 = albedo                        */
+    RT_MAT_METAL = 3,            /* material.rs:61-73   color = albedo, p0 = fuzz            */
+    RT_MAT_DIELECTRIC = 4,       /* material.rs:75-97   p0 = ior                             */
+    RT_MAT_ISOTROPIC = 5,        /* material.rs:99-113  tex0 = albedo                        */
+    RT_MAT_OREN_NAYAR = 6,       /* pbr.rs:12-42        tex0 = albedo, p0 = roughness        */
+    RT_MAT_BURLEY_DIFFUSE = 7,   /* pbr.rs:45-69        tex0 = albedo, p0 = roughness        */
+    RT_MAT_ROUGH_PLASTIC = 8,    /* pbr.rs:153-189      tex0 = spec, tex1 = diff, p0 = roughness, p1 = eta */
+    RT_MAT_DISNEY_DIFFUSE = 9,   /* pbr.rs:192-222      tex0 = albedo, p0 = roughness, p1 = subsurface */
+    RT_MAT_DISNEY_METAL = 10,    /* pbr.rs:224-278      tex0 = albedo, p0 = roughness, p1 = anisotropic, p2 = rot */
+    RT_MAT_DISNEY_SHEEN = 11,    /* pbr.rs:281-308      tex0 = albedo, p0 = tint             */
+    RT_MAT_DISNEY_CLEARCOAT = 12,/* pbr.rs:310-335      p0 = clearcoat_gloss                 */
+    RT_MAT__COUNT = 13
+};
+
+/* Texture tags, one per `impl Texture` (texture.rs). */
+enum RtTexType {
+    RT_TEX_CONSTANT = 0, /* texture.rs:15-23    color0 = col                                  */
+    RT_TEX_CHECKER = 1,  /* texture.rs:25-49    color0 = odd, color1 = even                    */
+    RT_TEX_PERLIN = 2,   /* texture.rs:153-168  scale, aux = index of the Perlin table set     */
+    RT_TEX_IMAGE = 3,    /* texture.rs:170-193  aux = image index                              */
+    RT_TEX__COUNT = 4
+};
+
+/* Sky models (demo_scene.rs:22-35; selected through lib.rs:11 SKY_COLOR). */
+enum RtSkyType {
+    RT_SKY_GRADIENT = 0, /* sky_color      demo_scene.rs:28-31 */
+    RT_SKY_BLACK = 1,    /* black_sky      demo_scene.rs:33-35 */
+    RT_SKY_ENV = 2       /* tex_sky_color  demo_scene.rs:22-26, image = sky_image */
+};
+
+#define RT_NO_TEX 0xFFFFFFFFu
+#define RT_PERLIN_POINTS 256u /* texture.rs:51 */
+
+/*
+ * Flattened structure-of-arrays scene.  Replaces `Vec<Arc<dyn Hitable>>` + the trait
+ * objects behind it (hitable.rs:57-62, material.rs, pbr.rs, texture.rs).  Only Sphere
+ * primitives are on the accelerated path (rect/box/medium are §8(f)).
+ */
+typedef struct RtFlatScene {
+    /* spheres: hitable.rs:57-62 `Sphere { c, r, mat, name }` in world-list order */
+    uint32_t n_spheres;
+    const float* sph_cx;   /* [n_spheres] */
+    const float* sph_cy;
+    const float* sph_cz;
+    const float* sph_r;
+    const uint32_t* sph_mat; /* [n_spheres] index into the material table */
+
+    /* materials */
+    uint32_t n_materials;
+    const uint8_t* mat_type;   /* [n_materials] RtMatType */
+    const float* mat_color;    /* [3*n_materials] Metal albedo; unused otherwise */
+    const float* mat_p0;       /* [n_materials] see RtMatType comments */
+    const float* mat_p1;
+    const float* mat_p2;
+    const float* mat_p3;
+    const uint32_t* mat_tex0;  /* [n_materials] texture index or RT_NO_TEX */
+    const uint32_t* mat_tex1;
+
+    /* textures */
+    uint32_t n_textures;
+    const uint8_t* tex_type;   /* [n_textures] RtTexType */
+    const float* tex_color0;   /* [3*n_textures] */
+    const float* tex_color1;   /* [3*n_textures] */
+    const float* tex_scale;    /* [n_textures] PerlinTex.scale */
+    const uint32_t* tex_aux;   /* [n_textures] perlin set index / image index */
+
+    /* Perlin table sets (texture.rs:53-91): rand_vec then perm_x, perm_y, perm_z */
+    uint32_t n_perlin;
+    const float* perlin_vec;    /* [n_perlin*256*3] xyz interleaved */
+    const uint16_t* perlin_perm;/* [n_perlin*3*256] values 0..255 */
+
+    /* images (texture.rs:170-181): Rgb<f32> = u8/255, row 0 = top of the file */
+    uint32_t n_images;
+    const uint32_t* img_w;      /* [n_images] */
+    const uint32_t* img_h;
+    const uint64_t* img_offset; /* [n_images] offset in floats into `texels` */
+    const float* texels;        /* RGB interleaved */
+    uint64_t n_texel_floats;
+
+    /* sky (lib.rs:11) */
+    uint32_t sky_type;  /* RtSkyType */
+    uint32_t sky_image; /* image index for RT_SKY_ENV (demo_scene.rs:19 ENV_TEX) */
+} RtFlatScene;
+
+/* camera.rs:7-10 — the four derived vectors of `Camera` (private fields there). */
+typedef struct RtCamera {
+    float origin[3];
+    float horizontal[3];
+    float vertical[3];
+    float lower_left_corner[3];
+} RtCamera;
+
+/*
+ * Render parameters.  Replaces the constants captured by the closure at main.rs:80:
+ * nx, ny (main.rs:66-67), samples_per_pixel (main.rs:64), MAX_DEPTH (main.rs:36) and
+ * the seed base 95 (main.rs:82).
+ */
+typedef struct RtParams {
+    uint32_t nx, ny;
+    uint32_t spp;
+    int32_t max_depth;   /* reference MAX_DEPTH = 50: segments with depth 0..=max_depth are traced */
+    uint64_t seed;       /* reference: 95 */
+    /* Row-interleaved sharding: image row j belongs to shard
+     * (j / shard_band) % shard_count.  shard_count <= 1 renders every row. */
+    uint32_t shard_band;
+    uint32_t shard_count;
+    uint32_t shard_id;
+    uint32_t spp_slice;  /* samples per pixel traced per wavefront slice; 0 = library default */
+    uint32_t flags;      /* RT_FLAG_* */
+    uint32_t reserved;
+} RtParams;
+
+#define RT_FLAG_NONE 0u
+
+typedef struct RtStats {
+    uint64_t n_paths;          /* nx_rows_local * nx * spp                                   */
+    uint64_t n_rays;           /* closest-hit queries = ray_color calls passing main.rs:40   */
+    uint64_t n_rays_secondary; /* n_rays - n_paths                                           */
+    uint64_t n_texture_fetches;/* ImageTex texel fetches (0 when not counted)                */
+    uint64_t n_bad_dir;        /* paths dropped where the reference would assert (main.rs:39) */
+    double seconds_total;      /* wall time of the render call, host clock                   */
+    double seconds_trace;      /* sum of trace+shade kernel time (HIP events, device clock)   */
+    double seconds_device;     /* all kernels of the call (HIP events)                       */
+    uint64_t bytes_algorithmic;/* 96*n_rays + 24*n_paths (+12*n_texture_fetches), SURVEY §8(d) */
+    uint64_t bytes_trace_algorithmic; /* trace kernel share: 48*n_rays + 48*n_secondary + 12*n_paths */
+    uint32_t n_trace_launches;
+    uint32_t n_slices;
+    uint64_t rays_per_depth[64]; /* rays traced at depth d (d < 64) */
+} RtStats;
+
+typedef struct RtCtx RtCtx;
+
+/* -- lifecycle ------------------------------------------------------------------------ */
+uint32_t rt_abi_version(void);
+/* Creates a context on HIP device `device_id`.  Replaces main.rs:72-73 (thread pool setup). */
+int rt_ctx_create(int device_id, RtCtx** out_ctx);
+void rt_ctx_destroy(RtCtx* ctx);
+/* Last error text of `ctx` (or of the calling thread's last failed rt_ctx_create if NULL). */
+const char* rt_last_error(const RtCtx* ctx);
+
+/* -- scene ---------------------------------------------------------------------------- */
+/* Validates and copies the flat scene to HBM (packed device records, Perlin tables,
+ * texel pool).  Replaces `let (world, cam) = scene(aspect)` hand-over at main.rs:74 and
+ * `SKY_COLOR.set` (demo_scene.rs:38).  May be called again to replace the scene. */
+int rt_scene_upload(RtCtx* ctx, const RtFlatScene* scene);
+
+/* Number of image rows owned by a shard, and the mapping local row -> image row. */
+uint32_t rt_shard_rows(uint32_t ny, uint32_t shard_band, uint32_t shard_count, uint32_t shard_id);
+uint32_t rt_shard_row_to_image_row(uint32_t local_row, uint32_t shard_band, uint32_t shard_count,
+                                   uint32_t shard_id);
+
+/* -- render --------------------------------------------------------------------------- */
+/*
+ * Renders the shard described by `params` and copies the result to host memory.
+ * Replaces the pixel loop main.rs:77-108 and the quantisation main.rs:98-105,127.
+ *   out_rgb_f32 : [rows_local*nx*3] linear radiance mean (c / spp, BEFORE gamma), local
+ *                 row 0 = lowest image row of the shard (reference j order).  May be NULL.
+ *   out_rgb8    : [rows_local*nx*3] gamma-2, *255.99 saturating u8, rows in DESCENDING j
+ *                 (i.e. flipped like main.rs:127).  May be NULL.
+ */
+int rt_render(RtCtx* ctx, const RtCamera* cam, const RtParams* params, float* out_rgb_f32,
+              uint8_t* out_rgb8, RtStats* stats);
+
+/*
+ * Same, but the f32 framebuffer stays in HBM: `d_out_rgb_f32` is a DEVICE pointer to
+ * rows_local*nx*3 floats (e.g. the storage of a tensor that RCCL will gather).  `stream`
+ * is a hipStream_t (NULL = the context's own stream); the call returns after the work has
+ * been enqueued and `stats` (if not NULL) forces a synchronisation to read the counters.
+ */
+int rt_render_device(RtCtx* ctx, const RtCamera* cam, const RtParams* params,
+                     void* d_out_rgb_f32, void* stream, RtStats* stats);
+
+/* -- single-bounce evaluation (test hook) --------------------------------------------------
+ * Runs ONE closest-hit + shade step (main.rs:44-58 for one depth) over `n` caller-given
+ * rays on the GPU without queue compaction and returns the per-ray outcome, so that each
+ * material / texture / sky branch can be compared with the CPU oracle function by
+ * function.  Arrays are host pointers, n entries each (vec3 as 3 floats).
+ */
+typedef struct RtBounceIO {
+    uint32_t n;
+    uint32_t depth;            /* RNG counter block = depth (see DESIGN.md "RNG") */
+    const float* in_o;         /* [3n] */
+    const float* in_d;         /* [3n] */
+    const uint32_t* in_key;    /* [2n] per-path RNG key (k0,k1) */
+    int32_t* out_hit;          /* [n] sphere index or -1 */
+    float* out_t;              /* [n] */
+    float* out_radiance;       /* [3n] emitted or sky term of this segment (untinted) */
+    float* out_attenuation;    /* [3n] */
+    float* out_o;              /* [3n] scattered ray */
+    float* out_d;              /* [3n] */
+    uint8_t* out_alive;        /* [n] 1 = scatter returned true */
+} RtBounceIO;
+int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTOW_MI355X_H */

@@ -1,0 +1,127 @@
+"""ctypes binding of liboracle.so (oracle/oracle.cpp).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ray_tracing_in_one_weekend_amd._ffi import RtBounceIO, RtCamera, RtFlatScene, RtParams, RtStats
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "liboracle.so")
+
+RNG_STREAM, RNG_COUNTER = 0, 1
+EST_RECURSIVE, EST_ITERATIVE = 0, 1
+ACCEL_LIST, ACCEL_BVH = 0, 1
+
+
+class OrcOptions(C.Structure):
+    _fields_ = [("rng_mode", C.c_uint32), ("estimator", C.c_uint32), ("accel", C.c_uint32),
+                ("n_threads", C.c_uint32), ("bvh_seed", C.c_uint64), ("bvh_skip_perlin", C.c_uint32),
+                ("seed_variant", C.c_uint32)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _DIR, "liboracle.so"], check=True)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    f = C.POINTER(C.c_float)
+    lib.orc_render.argtypes = [C.POINTER(RtFlatScene), C.POINTER(RtCamera), C.POINTER(RtParams),
+                               C.POINTER(OrcOptions), f, C.POINTER(C.c_uint8), C.POINTER(RtStats)]
+    lib.orc_render.restype = C.c_int
+    lib.orc_debug_bounce.argtypes = [C.POINTER(RtFlatScene), C.POINTER(RtBounceIO), C.c_uint32]
+    lib.orc_debug_bounce.restype = C.c_int
+    lib.orc_shard_rows.argtypes = [C.c_uint32] * 4
+    lib.orc_shard_rows.restype = C.c_uint32
+    lib.orc_xoshiro_from_state.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32]
+    lib.orc_smallrng_f32.argtypes = [C.c_uint64, C.c_int, f, C.c_uint32]
+    lib.orc_smallrng_state.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+    lib.orc_shuffle_u16.argtypes = [C.c_uint64, C.POINTER(C.c_uint16), C.c_uint32]
+    lib.orc_gen_range_usize.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
+    lib.orc_gen_range_usize.restype = C.c_uint64
+    lib.orc_ctr_path_key.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.orc_ctr_draw.argtypes = [C.c_uint32] * 3
+    lib.orc_ctr_draw.restype = C.c_uint32
+    lib.orc_sphere_get_uv.argtypes = [f, f]
+    lib.orc_camera_new.argtypes = [f, f, f, C.c_float, C.c_float, C.POINTER(RtCamera)]
+    lib.orc_camera_get_ray.argtypes = [C.POINTER(RtCamera), C.c_float, C.c_float, f, f]
+    lib.orc_sphere_hit.argtypes = [f, C.c_float, f, f, C.c_float, C.c_float, f]
+    lib.orc_sphere_hit.restype = C.c_int
+    lib.orc_offset_hit_point.argtypes = [f, f, f]
+    lib.orc_reflectance.argtypes = [C.c_float, C.c_float]
+    lib.orc_reflectance.restype = C.c_float
+    lib.orc_reflect.argtypes = [f, f, f]
+    lib.orc_refract.argtypes = [f, f, C.c_float, f]
+    lib.orc_sky_gradient.argtypes = [f, f]
+    lib.orc_texture_value.argtypes = [C.POINTER(RtFlatScene), C.c_uint32, f, f, f]
+    lib.orc_aabb_hit.argtypes = [f, f, f, f, C.c_float, C.c_float]
+    lib.orc_aabb_hit.restype = C.c_int
+    lib.orc_perlin_tables.argtypes = [C.c_uint64, C.c_uint32, f, C.POINTER(C.c_uint16)]
+    lib.orc_sphere_scene_layout.argtypes = [C.c_uint64, f]
+    lib.orc_sphere_scene_layout.restype = C.c_uint32
+    lib.orc_bvh_stats.argtypes = [C.POINTER(RtFlatScene), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.orc_bvh_stats.restype = C.c_uint32
+    _lib = lib
+    return lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def f3(v):
+    return np.asarray(v, dtype=np.float32).copy()
+
+
+def options(rng_mode=RNG_COUNTER, estimator=EST_RECURSIVE, accel=ACCEL_BVH, n_threads=0, bvh_seed=1995,
+            bvh_skip_perlin=0, seed_variant=0):
+    o = OrcOptions()
+    o.rng_mode, o.estimator, o.accel, o.n_threads = rng_mode, estimator, accel, n_threads
+    o.bvh_seed, o.bvh_skip_perlin, o.seed_variant = bvh_seed, bvh_skip_perlin, seed_variant
+    return o
+
+
+def render(flat_ptr, camera, params, opts, want_rgb8=False):
+    """flat_ptr: ctypes POINTER(RtFlatScene).  Returns (img [rows,nx,3] f32, rgb8|None, RtStats)."""
+    lib = load()
+    rows = lib.orc_shard_rows(params.ny, params.shard_band or 1, params.shard_count, params.shard_id)
+    img = np.zeros((rows, params.nx, 3), dtype=np.float32)
+    rgb8 = np.zeros((rows, params.nx, 3), dtype=np.uint8) if want_rgb8 else None
+    st = RtStats()
+    rc = lib.orc_render(flat_ptr, C.byref(camera), C.byref(params), C.byref(opts), _fp(img),
+                        rgb8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_rgb8 else None, C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"orc_render failed: {rc}")
+    return img, rgb8, st
+
+
+def debug_bounce(flat_ptr, origins, dirs, keys, depth=0, accel=ACCEL_LIST):
+    lib = load()
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+    k = np.ascontiguousarray(keys, dtype=np.uint32).reshape(-1, 2)
+    n = o.shape[0]
+    out = {"hit": np.zeros(n, np.int32), "t": np.zeros(n, np.float32), "radiance": np.zeros((n, 3), np.float32),
+           "attenuation": np.zeros((n, 3), np.float32), "o": np.zeros((n, 3), np.float32),
+           "d": np.zeros((n, 3), np.float32), "alive": np.zeros(n, np.uint8)}
+    io = RtBounceIO()
+    io.n, io.depth = n, depth
+    io.in_o, io.in_d, io.in_key = _fp(o), _fp(d), k.ctypes.data_as(C.POINTER(C.c_uint32))
+    io.out_hit = out["hit"].ctypes.data_as(C.POINTER(C.c_int32))
+    io.out_t, io.out_radiance, io.out_attenuation = _fp(out["t"]), _fp(out["radiance"]), _fp(out["attenuation"])
+    io.out_o, io.out_d = _fp(out["o"]), _fp(out["d"])
+    io.out_alive = out["alive"].ctypes.data_as(C.POINTER(C.c_uint8))
+    rc = lib.orc_debug_bounce(flat_ptr, C.byref(io), accel)
+    if rc != 0:
+        raise RuntimeError(f"orc_debug_bounce failed: {rc}")
+    return out

@@ -1,0 +1,9 @@
+"""MI355X-native wavefront path tracer behind the construction API of
+zhouhang95/ray_tracing_in_one_weekend."""
+from . import _ffi
+from ._ffi import (GpuLibraryMissing, RtCamera, RtFlatScene, RtParams, RtStats)
+from .api import Renderer, RtError, Scene, make_params
+from .images import decode_rgb32f, register_default_images, register_image
+
+__all__ = ["Renderer", "Scene", "RtError", "make_params", "RtCamera", "RtFlatScene", "RtParams", "RtStats",
+           "GpuLibraryMissing", "register_default_images", "register_image", "decode_rgb32f", "_ffi"]

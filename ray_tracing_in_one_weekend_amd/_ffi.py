@@ -1,0 +1,175 @@
+"""ctypes declarations of the two C ABIs (include/rtow_mi355x.h, include/rtow_host.h).
+
+Plumbing only: struct layouts, library loading and argument types.  The GPU library is
+mandatory for rendering; `load_gpu_library()` raises if it is missing — there is no CPU
+fallback in the product path.
+"""
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+GPU_LIB_PATH = os.path.join(_PKG_DIR, "librtow_mi355x.so")
+HOST_LIB_PATH = os.path.join(_PKG_DIR, "librtow_host.so")
+
+RT_NO_TEX = 0xFFFFFFFF
+RTH_INVALID = 0xFFFFFFFF
+
+# enum RtMatType
+(MAT_EMISSION, MAT_DIFFUSE, MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC, MAT_ISOTROPIC, MAT_OREN_NAYAR,
+ MAT_BURLEY_DIFFUSE, MAT_ROUGH_PLASTIC, MAT_DISNEY_DIFFUSE, MAT_DISNEY_METAL, MAT_DISNEY_SHEEN,
+ MAT_DISNEY_CLEARCOAT) = range(13)
+# enum RtTexType
+TEX_CONSTANT, TEX_CHECKER, TEX_PERLIN, TEX_IMAGE = range(4)
+# enum RtSkyType
+SKY_GRADIENT, SKY_BLACK, SKY_ENV = range(3)
+
+_f = C.POINTER(C.c_float)
+_u8 = C.POINTER(C.c_uint8)
+_u16 = C.POINTER(C.c_uint16)
+_u32 = C.POINTER(C.c_uint32)
+_u64 = C.POINTER(C.c_uint64)
+
+
+class RtFlatScene(C.Structure):
+    _fields_ = [
+        ("n_spheres", C.c_uint32),
+        ("sph_cx", _f), ("sph_cy", _f), ("sph_cz", _f), ("sph_r", _f), ("sph_mat", _u32),
+        ("n_materials", C.c_uint32),
+        ("mat_type", _u8), ("mat_color", _f), ("mat_p0", _f), ("mat_p1", _f), ("mat_p2", _f), ("mat_p3", _f),
+        ("mat_tex0", _u32), ("mat_tex1", _u32),
+        ("n_textures", C.c_uint32),
+        ("tex_type", _u8), ("tex_color0", _f), ("tex_color1", _f), ("tex_scale", _f), ("tex_aux", _u32),
+        ("n_perlin", C.c_uint32),
+        ("perlin_vec", _f), ("perlin_perm", _u16),
+        ("n_images", C.c_uint32),
+        ("img_w", _u32), ("img_h", _u32), ("img_offset", _u64), ("texels", _f), ("n_texel_floats", C.c_uint64),
+        ("sky_type", C.c_uint32), ("sky_image", C.c_uint32),
+    ]
+
+
+class RtCamera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("lower_left_corner", C.c_float * 3)]
+
+
+class RtParams(C.Structure):
+    _fields_ = [("nx", C.c_uint32), ("ny", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_int32),
+                ("seed", C.c_uint64), ("shard_band", C.c_uint32), ("shard_count", C.c_uint32),
+                ("shard_id", C.c_uint32), ("spp_slice", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("n_paths", C.c_uint64), ("n_rays", C.c_uint64), ("n_rays_secondary", C.c_uint64),
+                ("n_texture_fetches", C.c_uint64), ("n_bad_dir", C.c_uint64), ("seconds_total", C.c_double),
+                ("seconds_trace", C.c_double), ("seconds_device", C.c_double), ("bytes_algorithmic", C.c_uint64),
+                ("bytes_trace_algorithmic", C.c_uint64), ("n_trace_launches", C.c_uint32), ("n_slices", C.c_uint32),
+                ("rays_per_depth", C.c_uint64 * 64)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "rays_per_depth"}
+        d["rays_per_depth"] = list(self.rays_per_depth)
+        return d
+
+
+class RtBounceIO(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("depth", C.c_uint32), ("in_o", _f), ("in_d", _f), ("in_key", _u32),
+                ("out_hit", C.POINTER(C.c_int32)), ("out_t", _f), ("out_radiance", _f), ("out_attenuation", _f),
+                ("out_o", _f), ("out_d", _f), ("out_alive", _u8)]
+
+
+GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
+               "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce"]
+HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
+                "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
+                "rth_sphere", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
+                "rth_scene_camera", "rth_scene_sphere_name", "rth_scene_free"]
+
+_gpu_lib = None
+_host_lib = None
+
+
+class GpuLibraryMissing(RuntimeError):
+    pass
+
+
+def load_gpu_library():
+    """Loads librtow_mi355x.so (hand-written HIP kernels + C-ABI).  Raises if it is not built."""
+    global _gpu_lib
+    if _gpu_lib is not None:
+        return _gpu_lib
+    if not os.path.exists(GPU_LIB_PATH):
+        raise GpuLibraryMissing(
+            f"{GPU_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the render path.")
+    lib = C.CDLL(GPU_LIB_PATH)
+    vp = C.c_void_p
+    lib.rt_abi_version.restype = C.c_uint32
+    lib.rt_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.rt_ctx_create.restype = C.c_int
+    lib.rt_ctx_destroy.argtypes = [vp]
+    lib.rt_ctx_destroy.restype = None
+    lib.rt_last_error.argtypes = [vp]
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_scene_upload.argtypes = [vp, C.POINTER(RtFlatScene)]
+    lib.rt_scene_upload.restype = C.c_int
+    lib.rt_shard_rows.argtypes = [C.c_uint32] * 4
+    lib.rt_shard_rows.restype = C.c_uint32
+    lib.rt_shard_row_to_image_row.argtypes = [C.c_uint32] * 4
+    lib.rt_shard_row_to_image_row.restype = C.c_uint32
+    lib.rt_render.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), _f, _u8, C.POINTER(RtStats)]
+    lib.rt_render.restype = C.c_int
+    lib.rt_render_device.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), vp, vp, C.POINTER(RtStats)]
+    lib.rt_render_device.restype = C.c_int
+    lib.rt_debug_bounce.argtypes = [vp, C.POINTER(RtBounceIO)]
+    lib.rt_debug_bounce.restype = C.c_int
+    _gpu_lib = lib
+    return lib
+
+
+def load_host_library():
+    """Loads librtow_host.so (C++ mirror of the reference's construction API; no GPU code)."""
+    global _host_lib
+    if _host_lib is not None:
+        return _host_lib
+    if not os.path.exists(HOST_LIB_PATH):
+        raise RuntimeError(f"{HOST_LIB_PATH} is missing: run __graft_entry__.build()")
+    lib = C.CDLL(HOST_LIB_PATH)
+    vp = C.c_void_p
+    f3 = C.c_float * 3
+    lib.rth_last_error.restype = C.c_char_p
+    lib.rth_register_image.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, _f]
+    lib.rth_register_image.restype = C.c_int
+    lib.rth_rng_reseed.argtypes = [C.c_uint64]
+    lib.rth_rng_reseed.restype = None
+    lib.rth_scene_build.argtypes = [C.c_char_p, C.c_float, C.POINTER(vp)]
+    lib.rth_scene_build.restype = C.c_int
+    lib.rth_scene_new.argtypes = [C.POINTER(vp)]
+    lib.rth_scene_new.restype = C.c_int
+    lib.rth_tex_constant.argtypes = [vp, f3]
+    lib.rth_tex_constant.restype = C.c_uint32
+    lib.rth_tex_checker.argtypes = [vp, f3, f3]
+    lib.rth_tex_checker.restype = C.c_uint32
+    lib.rth_tex_perlin.argtypes = [vp, C.c_float]
+    lib.rth_tex_perlin.restype = C.c_uint32
+    lib.rth_tex_image.argtypes = [vp, C.c_char_p]
+    lib.rth_tex_image.restype = C.c_uint32
+    lib.rth_material.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, f3, C.c_float * 4]
+    lib.rth_material.restype = C.c_uint32
+    lib.rth_sphere.argtypes = [vp, f3, C.c_float, C.c_uint32, C.c_char_p]
+    lib.rth_sphere.restype = C.c_uint32
+    lib.rth_set_sky.argtypes = [vp, C.c_uint32, C.c_char_p]
+    lib.rth_set_sky.restype = C.c_int
+    lib.rth_set_camera.argtypes = [vp, f3, f3, f3, C.c_float, C.c_float]
+    lib.rth_set_camera.restype = C.c_int
+    lib.rth_scene_finish.argtypes = [vp, C.c_int]
+    lib.rth_scene_finish.restype = C.c_int
+    lib.rth_scene_flat.argtypes = [vp]
+    lib.rth_scene_flat.restype = C.POINTER(RtFlatScene)
+    lib.rth_scene_camera.argtypes = [vp, C.POINTER(RtCamera)]
+    lib.rth_scene_camera.restype = C.c_int
+    lib.rth_scene_sphere_name.argtypes = [vp, C.c_uint32]
+    lib.rth_scene_sphere_name.restype = C.c_char_p
+    lib.rth_scene_free.argtypes = [vp]
+    lib.rth_scene_free.restype = None
+    _host_lib = lib
+    return lib

@@ -1,0 +1,236 @@
+"""Host-side Python surface over the two C ABIs.
+
+`Scene` wraps the C++ mirror of the reference's constructors (librtow_host.so);
+`Renderer` wraps the GPU library (librtow_mi355x.so).  Nothing here computes pixels: every
+render call goes through the HIP kernels, and a missing GPU library raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import RtBounceIO, RtCamera, RtFlatScene, RtParams, RtStats
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class Scene:
+    """A flattened scene + camera built with the reference's constructors
+    (demo_scene.rs scene fns, or piecewise: textures -> materials -> spheres -> camera)."""
+
+    def __init__(self, handle):
+        self._lib = _ffi.load_host_library()
+        self._h = handle
+
+    # -- named scene functions (demo_scene.rs:37,229 + the two build-authored ones) --------
+    @classmethod
+    def build(cls, name, aspect_ratio):
+        lib = _ffi.load_host_library()
+        h = C.c_void_p()
+        rc = lib.rth_scene_build(name.encode(), C.c_float(aspect_ratio), C.byref(h))
+        if rc != 0:
+            raise RtError(lib.rth_last_error().decode())
+        return cls(h)
+
+    # -- piecewise construction ----------------------------------------------------------------
+    @classmethod
+    def new(cls):
+        lib = _ffi.load_host_library()
+        h = C.c_void_p()
+        if lib.rth_scene_new(C.byref(h)) != 0:
+            raise RtError(lib.rth_last_error().decode())
+        return cls(h)
+
+    def _check(self, handle):
+        if handle == _ffi.RTH_INVALID:
+            raise RtError(self._lib.rth_last_error().decode())
+        return handle
+
+    def constant_tex(self, col):
+        return self._check(self._lib.rth_tex_constant(self._h, _f3(col)))
+
+    def checker_tex(self, odd, even):
+        return self._check(self._lib.rth_tex_checker(self._h, _f3(odd), _f3(even)))
+
+    def perlin_tex(self, scale):
+        return self._check(self._lib.rth_tex_perlin(self._h, C.c_float(scale)))
+
+    def image_tex(self, path):
+        return self._check(self._lib.rth_tex_image(self._h, path.encode()))
+
+    def material(self, mat_type, tex0=_ffi.RTH_INVALID, tex1=_ffi.RTH_INVALID, color=(0, 0, 0), p=(0, 0, 0, 0)):
+        p = list(p) + [0.0] * (4 - len(p))
+        return self._check(self._lib.rth_material(self._h, mat_type, tex0, tex1, _f3(color),
+                                                  (C.c_float * 4)(*[float(x) for x in p])))
+
+    def sphere(self, c, r, material, name=""):
+        return self._check(self._lib.rth_sphere(self._h, _f3(c), C.c_float(r), material, name.encode()))
+
+    def set_sky(self, sky, env_path=None):
+        if self._lib.rth_set_sky(self._h, sky, env_path.encode() if env_path else None) != 0:
+            raise RtError(self._lib.rth_last_error().decode())
+
+    def set_camera(self, lookfrom, lookat, vup, vfov, aspect_ratio):
+        if self._lib.rth_set_camera(self._h, _f3(lookfrom), _f3(lookat), _f3(vup), C.c_float(vfov),
+                                    C.c_float(aspect_ratio)) != 0:
+            raise RtError(self._lib.rth_last_error().decode())
+
+    def finish(self, use_bvh=True):
+        if self._lib.rth_scene_finish(self._h, 1 if use_bvh else 0) != 0:
+            raise RtError(self._lib.rth_last_error().decode())
+        return self
+
+    # -- accessors ----------------------------------------------------------------------------------
+    @property
+    def flat(self):
+        p = self._lib.rth_scene_flat(self._h)
+        if not p:
+            raise RtError("scene not finished")
+        return p.contents
+
+    @property
+    def flat_ptr(self):
+        p = self._lib.rth_scene_flat(self._h)
+        if not p:
+            raise RtError("scene not finished")
+        return p
+
+    @property
+    def camera(self):
+        cam = RtCamera()
+        if self._lib.rth_scene_camera(self._h, C.byref(cam)) != 0:
+            raise RtError("scene not finished")
+        return cam
+
+    def sphere_name(self, i):
+        return self._lib.rth_scene_sphere_name(self._h, i).decode()
+
+    def arrays(self):
+        """numpy copies of the flat arrays (for tests and inspection)."""
+        fs = self.flat
+
+        def arr(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+        ns, nm, nt = fs.n_spheres, fs.n_materials, fs.n_textures
+        return {
+            "sph_cx": arr(fs.sph_cx, ns, np.float32), "sph_cy": arr(fs.sph_cy, ns, np.float32),
+            "sph_cz": arr(fs.sph_cz, ns, np.float32), "sph_r": arr(fs.sph_r, ns, np.float32),
+            "sph_mat": arr(fs.sph_mat, ns, np.uint32),
+            "mat_type": arr(fs.mat_type, nm, np.uint8), "mat_color": arr(fs.mat_color, 3 * nm, np.float32),
+            "mat_p0": arr(fs.mat_p0, nm, np.float32), "mat_p1": arr(fs.mat_p1, nm, np.float32),
+            "mat_p2": arr(fs.mat_p2, nm, np.float32), "mat_p3": arr(fs.mat_p3, nm, np.float32),
+            "mat_tex0": arr(fs.mat_tex0, nm, np.uint32), "mat_tex1": arr(fs.mat_tex1, nm, np.uint32),
+            "tex_type": arr(fs.tex_type, nt, np.uint8), "tex_color0": arr(fs.tex_color0, 3 * nt, np.float32),
+            "tex_color1": arr(fs.tex_color1, 3 * nt, np.float32), "tex_scale": arr(fs.tex_scale, nt, np.float32),
+            "tex_aux": arr(fs.tex_aux, nt, np.uint32),
+            "perlin_vec": arr(fs.perlin_vec, fs.n_perlin * 768, np.float32),
+            "perlin_perm": arr(fs.perlin_perm, fs.n_perlin * 768, np.uint16),
+            "img_w": arr(fs.img_w, fs.n_images, np.uint32), "img_h": arr(fs.img_h, fs.n_images, np.uint32),
+            "sky_type": fs.sky_type, "sky_image": fs.sky_image,
+        }
+
+    def close(self):
+        if self._h:
+            self._lib.rth_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_params(nx, ny, spp, max_depth=50, seed=95, shard_band=0, shard_count=1, shard_id=0, spp_slice=0):
+    p = RtParams()
+    p.nx, p.ny, p.spp, p.max_depth, p.seed = nx, ny, spp, max_depth, seed
+    p.shard_band, p.shard_count, p.shard_id, p.spp_slice = shard_band, shard_count, shard_id, spp_slice
+    return p
+
+
+class Renderer:
+    """One GPU context (rt_ctx_create).  Replaces the render half of main.rs:62-129."""
+
+    def __init__(self, device=0):
+        self._lib = _ffi.load_gpu_library()  # raises GpuLibraryMissing: no fallback
+        self._ctx = C.c_void_p()
+        rc = self._lib.rt_ctx_create(device, C.byref(self._ctx))
+        if rc != 0:
+            raise RtError(f"rt_ctx_create({device}) failed ({rc}): {self._lib.rt_last_error(None).decode()}")
+        self.device = device
+
+    def _raise(self, what, rc):
+        raise RtError(f"{what} failed ({rc}): {self._lib.rt_last_error(self._ctx).decode()}")
+
+    def upload(self, scene):
+        ptr = scene.flat_ptr if isinstance(scene, Scene) else C.pointer(scene)
+        rc = self._lib.rt_scene_upload(self._ctx, ptr)
+        if rc != 0:
+            self._raise("rt_scene_upload", rc)
+
+    def shard_rows(self, params):
+        return self._lib.rt_shard_rows(params.ny, params.shard_band or 1, params.shard_count, params.shard_id)
+
+    def render(self, camera, params, want_rgb8=False):
+        """Returns (f32 image [rows, nx, 3] (row 0 = bottom), rgb8 or None, RtStats)."""
+        rows = self.shard_rows(params)
+        img = np.zeros((rows, params.nx, 3), dtype=np.float32)
+        rgb8 = np.zeros((rows, params.nx, 3), dtype=np.uint8) if want_rgb8 else None
+        stats = RtStats()
+        rc = self._lib.rt_render(self._ctx, C.byref(camera), C.byref(params),
+                                 img.ctypes.data_as(C.POINTER(C.c_float)),
+                                 rgb8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_rgb8 else None, C.byref(stats))
+        if rc != 0:
+            self._raise("rt_render", rc)
+        return img, rgb8, stats
+
+    def render_device(self, camera, params, device_ptr, stream=None, want_stats=True):
+        """Renders into HBM at `device_ptr` (e.g. torch_tensor.data_ptr()); nothing crosses PCIe."""
+        stats = RtStats()
+        rc = self._lib.rt_render_device(self._ctx, C.byref(camera), C.byref(params), C.c_void_p(device_ptr),
+                                        C.c_void_p(stream) if stream else None,
+                                        C.byref(stats) if want_stats else None)
+        if rc != 0:
+            self._raise("rt_render_device", rc)
+        return stats
+
+    def debug_bounce(self, origins, dirs, keys, depth=0):
+        """One closest-hit + shade step for caller-given rays (rt_debug_bounce)."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        k = np.ascontiguousarray(keys, dtype=np.uint32).reshape(-1, 2)
+        n = o.shape[0]
+        out = {"hit": np.zeros(n, np.int32), "t": np.zeros(n, np.float32), "radiance": np.zeros((n, 3), np.float32),
+               "attenuation": np.zeros((n, 3), np.float32), "o": np.zeros((n, 3), np.float32),
+               "d": np.zeros((n, 3), np.float32), "alive": np.zeros(n, np.uint8)}
+        io = RtBounceIO()
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        io.n, io.depth = n, depth
+        io.in_o, io.in_d, io.in_key = fp(o), fp(d), k.ctypes.data_as(C.POINTER(C.c_uint32))
+        io.out_hit = out["hit"].ctypes.data_as(C.POINTER(C.c_int32))
+        io.out_t, io.out_radiance, io.out_attenuation = fp(out["t"]), fp(out["radiance"]), fp(out["attenuation"])
+        io.out_o, io.out_d = fp(out["o"]), fp(out["d"])
+        io.out_alive = out["alive"].ctypes.data_as(C.POINTER(C.c_uint8))
+        rc = self._lib.rt_debug_bounce(self._ctx, C.byref(io))
+        if rc != 0:
+            self._raise("rt_debug_bounce", rc)
+        return out
+
+    def close(self):
+        if self._ctx:
+            self._lib.rt_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

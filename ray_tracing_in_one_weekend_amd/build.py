@@ -1,0 +1,63 @@
+"""Build recipes for the native libraries (in-tree, so the built .so travels with the repo
+snapshot to the GPU box).  hipcc cross-compiles gfx950 without a GPU."""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout)
+    return r.stdout
+
+
+def build_gpu_library(force=False):
+    """hipcc --offload-arch=gfx950: HIP kernels + C-ABI -> librtow_mi355x.so"""
+    csrc = os.path.join(PKG_DIR, "csrc")
+    srcs = [os.path.join(csrc, f) for f in ("rt_api.hip", "rt_kernels.h", "rt_device.h")]
+    srcs.append(os.path.join(ROOT, "include", "rtow_mi355x.h"))
+    out = os.path.join(PKG_DIR, "librtow_mi355x.so")
+    if force or _newer(out, srcs):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        _run([hipcc] + HIPCC_FLAGS + ["-o", out, srcs[0]])
+    return out
+
+
+def build_host_library(force=False):
+    """g++: C++ mirror of the reference construction API + C handle API -> librtow_host.so"""
+    host = os.path.join(PKG_DIR, "host")
+    srcs = [os.path.join(host, f) for f in ("demo_scene.cpp", "host_capi.cpp", "rtow.hpp")]
+    srcs += [os.path.join(ROOT, "include", f) for f in ("rtow_mi355x.h", "rtow_host.h")]
+    out = os.path.join(PKG_DIR, "librtow_host.so")
+    if force or _newer(out, srcs):
+        _run(["g++"] + HOST_FLAGS + ["-o", out, srcs[0], srcs[1]])
+    return out
+
+
+def build_oracle(force=False):
+    """g++: CPU restatement used by tests / smoke / bench cpu_baseline only."""
+    odir = os.path.join(ROOT, "oracle")
+    out = os.path.join(odir, "liboracle.so")
+    srcs = [os.path.join(odir, "oracle.cpp"), os.path.join(ROOT, "include", "rtow_mi355x.h")]
+    if force or _newer(out, srcs):
+        _run(["make", "-C", odir, "-B" if force else "-s", "liboracle.so"])
+    return out
+
+
+def build_all(force=False):
+    return [build_gpu_library(force), build_host_library(force), build_oracle(force)]

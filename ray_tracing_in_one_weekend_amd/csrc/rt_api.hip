@@ -1,0 +1,496 @@
+// rt_api.hip — implementation of the C-ABI in include/rtow_mi355x.h on top of the gfx950
+// wavefront kernels (rt_kernels.h).  One context = one GPU = one HIP stream; the bounce loop
+// of a slice is enqueued without any host synchronisation (queue sizes live in HBM).
+#include "../../include/rtow_mi355x.h"
+#include "rt_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct RtCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    bool has_scene = false;
+    DevScene ds{};
+    std::vector<void*> scene_allocs;
+    // work buffers (grown on demand, reused across calls)
+    DevBuf qbuf[6];   // two queues x (a, b, c)
+    DevBuf rad, acc, counts, totals, out_f32, out_u8, dbg;
+    std::vector<hipEvent_t> events;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    int n_cu = 256;
+};
+
+namespace {
+
+int fail(RtCtx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define RT_HIP(ctx, expr)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) {                                                                           \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE,                    \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                               \
+        }                                                                                                  \
+    } while (0)
+
+int ensure(RtCtx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return RT_OK;
+    if (b.p) {
+        RT_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    RT_HIP(ctx, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return RT_OK;
+}
+
+void free_buf(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+void free_scene(RtCtx* ctx) {
+    for (void* p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->has_scene = false;
+    std::memset(&ctx->ds, 0, sizeof(ctx->ds));
+}
+
+template <class T>
+int upload(RtCtx* ctx, const std::vector<T>& host, const T** dev) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
+    RT_HIP(ctx, hipMalloc(&p, bytes));
+    ctx->scene_allocs.push_back(p);
+    if (!host.empty()) RT_HIP(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = reinterpret_cast<const T*>(p);
+    return RT_OK;
+}
+
+bool mat_needs_tex0(uint32_t t) {
+    return t == RT_MAT_EMISSION || t == RT_MAT_DIFFUSE || t == RT_MAT_LAMBERT || t == RT_MAT_ISOTROPIC ||
+           t == RT_MAT_OREN_NAYAR || t == RT_MAT_BURLEY_DIFFUSE || t == RT_MAT_ROUGH_PLASTIC ||
+           t == RT_MAT_DISNEY_DIFFUSE || t == RT_MAT_DISNEY_METAL || t == RT_MAT_DISNEY_SHEEN;
+}
+
+struct SliceTiming {
+    hipEvent_t t0, t1;
+};
+
+} // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char* rt_last_error(const RtCtx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_ctx_create(int device_id, RtCtx** out_ctx) {
+    if (!out_ctx) {
+        g_create_error = "rt_ctx_create: out_ctx is NULL";
+        return RT_ERR_INVALID;
+    }
+    *out_ctx = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_create_error = std::string("rt_ctx_create: no HIP device available (") + hipGetErrorString(e) + ")";
+        return RT_ERR_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n_dev) {
+        g_create_error = "rt_ctx_create: device_id out of range";
+        return RT_ERR_INVALID;
+    }
+    RtCtx* ctx = new (std::nothrow) RtCtx();
+    if (!ctx) {
+        g_create_error = "rt_ctx_create: out of host memory";
+        return RT_ERR_NOMEM;
+    }
+    ctx->device = device_id;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string("rt_ctx_create: ") + what + ": " + hipGetErrorString(err);
+        delete ctx;
+        return RT_ERR_DEVICE;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail("hipEventCreate", e);
+    *out_ctx = ctx;
+    return RT_OK;
+}
+
+void rt_ctx_destroy(RtCtx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    for (auto& b : ctx->qbuf) free_buf(b);
+    free_buf(ctx->rad), free_buf(ctx->acc), free_buf(ctx->counts), free_buf(ctx->totals);
+    free_buf(ctx->out_f32), free_buf(ctx->out_u8), free_buf(ctx->dbg);
+    for (auto ev : ctx->events) (void)hipEventDestroy(ev);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+uint32_t rt_shard_rows(uint32_t ny, uint32_t shard_band, uint32_t shard_count, uint32_t shard_id) {
+    if (shard_count <= 1) return ny;
+    if (shard_band == 0) shard_band = 1;
+    uint32_t n = 0;
+    for (uint32_t j = 0; j < ny; ++j)
+        if ((j / shard_band) % shard_count == shard_id) ++n;
+    return n;
+}
+
+uint32_t rt_shard_row_to_image_row(uint32_t local_row, uint32_t shard_band, uint32_t shard_count, uint32_t shard_id) {
+    if (shard_count <= 1) return local_row;
+    if (shard_band == 0) shard_band = 1;
+    return ((local_row / shard_band) * shard_count + shard_id) * shard_band + (local_row % shard_band);
+}
+
+int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!s) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: scene is NULL");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    // ---- validate ---------------------------------------------------------------------------
+    if (s->n_spheres && (!s->sph_cx || !s->sph_cy || !s->sph_cz || !s->sph_r || !s->sph_mat))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: sphere arrays missing");
+    if (s->n_materials && (!s->mat_type || !s->mat_color || !s->mat_p0 || !s->mat_p1 || !s->mat_p2 || !s->mat_p3 ||
+                           !s->mat_tex0 || !s->mat_tex1))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: material arrays missing");
+    if (s->n_textures && (!s->tex_type || !s->tex_color0 || !s->tex_color1 || !s->tex_scale || !s->tex_aux))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: texture arrays missing");
+    if (s->n_perlin && (!s->perlin_vec || !s->perlin_perm))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: perlin tables missing");
+    if (s->n_images && (!s->img_w || !s->img_h || !s->img_offset || !s->texels))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: image arrays missing");
+    for (uint32_t i = 0; i < s->n_spheres; ++i)
+        if (s->sph_mat[i] >= s->n_materials)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: sphere " + std::to_string(i) + " has material index out of range");
+    for (uint32_t m = 0; m < s->n_materials; ++m) {
+        uint32_t t = s->mat_type[m];
+        if (t >= RT_MAT__COUNT) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: unknown material type");
+        if (mat_needs_tex0(t) && s->mat_tex0[m] >= s->n_textures)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: material " + std::to_string(m) + " needs tex0");
+        if (t == RT_MAT_ROUGH_PLASTIC && s->mat_tex1[m] >= s->n_textures)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: RoughPlastic material needs tex1");
+    }
+    for (uint32_t t = 0; t < s->n_textures; ++t) {
+        uint32_t ty = s->tex_type[t];
+        if (ty >= RT_TEX__COUNT) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: unknown texture type");
+        if (ty == RT_TEX_PERLIN && s->tex_aux[t] >= s->n_perlin)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: Perlin texture references a missing table set");
+        if (ty == RT_TEX_IMAGE && s->tex_aux[t] >= s->n_images)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: image texture references a missing image");
+    }
+    for (uint32_t k = 0; k < s->n_perlin * 3u * RT_PERLIN_POINTS; ++k)
+        if (s->perlin_perm[k] >= RT_PERLIN_POINTS)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: perlin permutation entry out of range");
+    uint64_t n_texels = 0;
+    for (uint32_t k = 0; k < s->n_images; ++k) {
+        if (s->img_w[k] == 0 || s->img_h[k] == 0) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: empty image");
+        if (s->img_offset[k] % 3u) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: image offset not a multiple of 3");
+        uint64_t end = s->img_offset[k] + 3ull * s->img_w[k] * s->img_h[k];
+        if (end > s->n_texel_floats) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: image exceeds texel pool");
+        n_texels = std::max(n_texels, end / 3u);
+    }
+    if (s->sky_type > RT_SKY_ENV) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: unknown sky type");
+    if (s->sky_type == RT_SKY_ENV && s->sky_image >= s->n_images)
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: env sky references a missing image");
+
+    // ---- pack -------------------------------------------------------------------------------
+    std::vector<float4> geo(s->n_spheres);
+    std::vector<uint32_t> smat(s->n_spheres);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        geo[i] = make_float4(s->sph_cx[i], s->sph_cy[i], s->sph_cz[i], s->sph_r[i]);
+        smat[i] = s->sph_mat[i];
+    }
+    std::vector<MatRec> mats(s->n_materials);
+    for (uint32_t m = 0; m < s->n_materials; ++m) {
+        MatRec r{};
+        r.type = s->mat_type[m];
+        r.tex0 = s->mat_tex0[m];
+        r.tex1 = s->mat_tex1[m];
+        r.cr = s->mat_color[3 * m], r.cg = s->mat_color[3 * m + 1], r.cb = s->mat_color[3 * m + 2];
+        r.p0 = s->mat_p0[m], r.p1 = s->mat_p1[m], r.p2 = s->mat_p2[m], r.p3 = s->mat_p3[m];
+        mats[m] = r;
+    }
+    std::vector<TexRec> texs(s->n_textures);
+    for (uint32_t t = 0; t < s->n_textures; ++t) {
+        TexRec r{};
+        r.type = s->tex_type[t];
+        r.aux = s->tex_aux[t];
+        r.scale = s->tex_scale[t];
+        r.c0r = s->tex_color0[3 * t], r.c0g = s->tex_color0[3 * t + 1], r.c0b = s->tex_color0[3 * t + 2];
+        r.c1r = s->tex_color1[3 * t], r.c1g = s->tex_color1[3 * t + 1], r.c1b = s->tex_color1[3 * t + 2];
+        texs[t] = r;
+    }
+    std::vector<float4> pvec((size_t)s->n_perlin * 256);
+    std::vector<uint8_t> pperm((size_t)s->n_perlin * 768);
+    for (size_t k = 0; k < pvec.size(); ++k)
+        pvec[k] = make_float4(s->perlin_vec[3 * k], s->perlin_vec[3 * k + 1], s->perlin_vec[3 * k + 2], 0.0f);
+    for (size_t k = 0; k < pperm.size(); ++k) pperm[k] = (uint8_t)s->perlin_perm[k];
+    std::vector<ImgRec> imgs(s->n_images);
+    std::vector<float4> texels((size_t)n_texels);
+    for (uint32_t k = 0; k < s->n_images; ++k) {
+        uint64_t off = s->img_offset[k] / 3u;
+        imgs[k] = ImgRec{s->img_w[k], s->img_h[k], (uint32_t)off, (uint32_t)(off >> 32)};
+        const float* src = s->texels + s->img_offset[k];
+        const size_t np = (size_t)s->img_w[k] * s->img_h[k];
+        for (size_t p = 0; p < np; ++p) texels[off + p] = make_float4(src[3 * p], src[3 * p + 1], src[3 * p + 2], 0.0f);
+    }
+
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    DevScene ds{};
+    ds.n_spheres = s->n_spheres, ds.n_materials = s->n_materials, ds.n_textures = s->n_textures;
+    ds.n_perlin = s->n_perlin, ds.n_images = s->n_images, ds.sky_type = s->sky_type, ds.sky_image = s->sky_image;
+    int rc;
+    if ((rc = upload(ctx, geo, &ds.sph_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
+        (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
+        (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
+        (rc = upload(ctx, texels, &ds.texels))) {
+        free_scene(ctx);
+        return rc;
+    }
+    ctx->ds = ds;
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+static int check_params(RtCtx* ctx, const RtCamera* cam, const RtParams* p) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_STATE, "render: no scene uploaded");
+    if (!cam || !p) return fail(ctx, RT_ERR_INVALID, "render: camera/params NULL");
+    if (p->nx == 0 || p->ny == 0 || p->spp == 0) return fail(ctx, RT_ERR_INVALID, "render: nx, ny and spp must be > 0");
+    if (p->max_depth < 0 || p->max_depth > 4096) return fail(ctx, RT_ERR_INVALID, "render: max_depth out of range [0, 4096]");
+    if ((uint64_t)p->nx * p->ny > 0xFFFFFFFFull) return fail(ctx, RT_ERR_INVALID, "render: image too large");
+    if (p->shard_count > 1 && p->shard_id >= p->shard_count) return fail(ctx, RT_ERR_INVALID, "render: shard_id >= shard_count");
+    return RT_OK;
+}
+
+static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, void* d_out_rgb_f32, void* d_out_rgb8,
+                       void* stream_v, RtStats* stats) {
+    int rc = check_params(ctx, cam, prm);
+    if (rc) return rc;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    const auto wall0 = std::chrono::steady_clock::now();
+
+    const uint32_t nx = prm->nx, ny = prm->ny, spp = prm->spp;
+    const uint32_t band = prm->shard_band ? prm->shard_band : 1u;
+    const uint32_t scount = prm->shard_count <= 1 ? 1u : prm->shard_count;
+    const uint32_t rows = rt_shard_rows(ny, band, scount, prm->shard_id);
+    const uint64_t npix64 = (uint64_t)rows * nx;
+    if (npix64 == 0) {
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        return RT_OK;
+    }
+    const uint32_t npix = (uint32_t)npix64;
+    // slice size: bound the ray queue to ~32 Mi rays (3 GiB of queues), at least one sample
+    uint32_t S = prm->spp_slice;
+    if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (32ull << 20) / npix64);
+    S = std::min(S, spp);
+    if ((uint64_t)S * npix64 > 0xFFFFFF00ull) S = (uint32_t)(0xFFFFFF00ull / npix64);
+    if (S == 0) return fail(ctx, RT_ERR_UNSUPPORTED, "render: shard has more than 2^32 pixels");
+    const uint32_t n_slices = (spp + S - 1) / S;
+    const uint32_t n_max = npix * S;
+    const uint32_t nq = 32;
+    const uint32_t nchunks = (n_max + 255u) / 256u;
+    const uint32_t cap = ((nchunks + nq - 1) / nq) * 256u;
+    const int n_depths = prm->max_depth + 1;
+    const uint32_t blocks_per_shard = (uint32_t)std::max(1, (ctx->n_cu * 8) / (int)nq);
+    const uint32_t grid = nq * blocks_per_shard;
+
+    const size_t qbytes = (size_t)nq * cap * sizeof(float4);
+    for (auto& b : ctx->qbuf)
+        if ((rc = ensure(ctx, b, qbytes))) return rc;
+    if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * 3 * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->acc, (size_t)npix * 3 * sizeof(float)))) return rc;
+    const size_t counts_bytes = (size_t)(n_depths + 1) * nq * sizeof(uint32_t);
+    if ((rc = ensure(ctx, ctx->counts, counts_bytes))) return rc;
+    const size_t totals_bytes = (size_t)(n_depths + 2) * sizeof(unsigned long long);
+    if ((rc = ensure(ctx, ctx->totals, totals_bytes))) return rc;
+    while (ctx->events.size() < 2 * (size_t)n_slices) {
+        hipEvent_t ev;
+        RT_HIP(ctx, hipEventCreate(&ev));
+        ctx->events.push_back(ev);
+    }
+    Queue Q[2];
+    Q[0] = Queue{(float4*)ctx->qbuf[0].p, (float4*)ctx->qbuf[1].p, (float4*)ctx->qbuf[2].p};
+    Q[1] = Queue{(float4*)ctx->qbuf[3].p, (float4*)ctx->qbuf[4].p, (float4*)ctx->qbuf[5].p};
+    float* rad = (float*)ctx->rad.p;
+    float* acc = (float*)ctx->acc.p;
+    uint32_t* counts = (uint32_t*)ctx->counts.p;
+    unsigned long long* totals = (unsigned long long*)ctx->totals.p; // [0]=tex fetches [1]=bad dirs [2..]=rays per depth
+
+    const size_t lds_bytes = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
+
+    RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
+    RT_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * 3 * sizeof(float), st));
+    RT_HIP(ctx, hipMemsetAsync(totals, 0, totals_bytes, st));
+
+    GenParams gp{};
+    for (int k = 0; k < 3; ++k) {
+        gp.cam_origin[k] = cam->origin[k];
+        gp.cam_horizontal[k] = cam->horizontal[k];
+        gp.cam_vertical[k] = cam->vertical[k];
+        gp.cam_llc[k] = cam->lower_left_corner[k];
+    }
+    gp.nx = nx, gp.ny = ny, gp.npix = npix;
+    gp.shard_band = band, gp.shard_count = scount, gp.shard_id = prm->shard_id;
+    gp.nq = nq, gp.cap = cap;
+    gp.seed_lo = (uint32_t)prm->seed, gp.seed_hi = (uint32_t)(prm->seed >> 32);
+
+    uint32_t n_trace_launches = 0;
+    for (uint32_t sl = 0; sl < n_slices; ++sl) {
+        const uint32_t s0 = sl * S;
+        const uint32_t sc = std::min(S, spp - s0);
+        gp.s0 = s0;
+        gp.n_rays = npix * sc;
+        RT_HIP(ctx, hipMemsetAsync(counts, 0, counts_bytes, st));
+        hipLaunchKernelGGL(k_gen_primary, dim3((gp.n_rays + 255u) / 256u), dim3(256), 0, st, gp, Q[0], counts);
+        RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl], st));
+        for (int depth = 0; depth < n_depths; ++depth) {
+            TraceParams tp{nq, cap, depth, prm->max_depth};
+            hipLaunchKernelGGL(k_trace_shade, dim3(grid), dim3(256), lds_bytes, st, ctx->ds, Q[depth & 1], Q[(depth + 1) & 1],
+                               counts + (size_t)depth * nq, counts + (size_t)(depth + 1) * nq, rad, tp, totals);
+            ++n_trace_launches;
+        }
+        RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl + 1], st));
+        hipLaunchKernelGGL(k_resolve, dim3((npix + 255u) / 256u), dim3(256), 0, st, rad, acc, npix, sc);
+        hipLaunchKernelGGL(k_accum_counts, dim3((n_depths + 63) / 64), dim3(64), 0, st, counts, nq, (uint32_t)n_depths, totals + 2);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((npix + 255u) / 256u), dim3(256), 0, st, acc, (float*)d_out_rgb_f32,
+                       (uint8_t*)d_out_rgb8, nx, rows, spp);
+    RT_HIP(ctx, hipEventRecord(ctx->ev_end, st));
+    RT_HIP(ctx, hipGetLastError());
+
+    if (stats) {
+        RT_HIP(ctx, hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)n_depths + 2);
+        RT_HIP(ctx, hipMemcpy(h.data(), totals, totals_bytes, hipMemcpyDeviceToHost));
+        std::memset(stats, 0, sizeof(*stats));
+        stats->n_paths = (uint64_t)npix * spp;
+        stats->n_texture_fetches = h[0];
+        stats->n_bad_dir = h[1];
+        for (int d = 0; d < n_depths; ++d) {
+            stats->n_rays += h[(size_t)d + 2];
+            if (d < 64) stats->rays_per_depth[d] = h[(size_t)d + 2];
+        }
+        stats->n_rays_secondary = stats->n_rays - std::min(stats->n_rays, stats->n_paths);
+        float ms = 0.0f;
+        double trace_ms = 0.0;
+        for (uint32_t sl = 0; sl < n_slices; ++sl) {
+            RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[2 * sl], ctx->events[2 * sl + 1]));
+            trace_ms += ms;
+        }
+        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        stats->seconds_trace = trace_ms * 1e-3;
+        stats->seconds_device = ms * 1e-3;
+        stats->bytes_algorithmic = 96ull * stats->n_rays + 24ull * stats->n_paths + 12ull * stats->n_texture_fetches;
+        stats->bytes_trace_algorithmic = 48ull * stats->n_rays + 48ull * stats->n_rays_secondary + 12ull * stats->n_paths;
+        stats->n_trace_launches = n_trace_launches;
+        stats->n_slices = n_slices;
+        stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    return RT_OK;
+}
+
+int rt_render_device(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, void* d_out_rgb_f32, void* stream_v,
+                     RtStats* stats) {
+    if (ctx && !d_out_rgb_f32) return fail(ctx, RT_ERR_INVALID, "rt_render_device: output pointer is NULL");
+    return render_impl(ctx, cam, prm, d_out_rgb_f32, nullptr, stream_v, stats);
+}
+
+int rt_render(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, float* out_rgb_f32, uint8_t* out_rgb8, RtStats* stats) {
+    int rc = check_params(ctx, cam, prm);
+    if (rc) return rc;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t band = prm->shard_band ? prm->shard_band : 1u;
+    const uint32_t rows = rt_shard_rows(prm->ny, band, prm->shard_count, prm->shard_id);
+    const size_t n = (size_t)rows * prm->nx * 3;
+    if ((rc = ensure(ctx, ctx->out_f32, n * sizeof(float)))) return rc;
+    // the u8 image is produced only on request
+    if (out_rgb8 && (rc = ensure(ctx, ctx->out_u8, n))) return rc;
+    RtStats local;
+    rc = render_impl(ctx, cam, prm, ctx->out_f32.p, out_rgb8 ? ctx->out_u8.p : nullptr, nullptr, stats ? stats : &local);
+    if (rc) return rc;
+    const auto w0 = std::chrono::steady_clock::now();
+    if (out_rgb_f32 && n) RT_HIP(ctx, hipMemcpy(out_rgb_f32, ctx->out_f32.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_rgb8 && n) RT_HIP(ctx, hipMemcpy(out_rgb8, ctx->out_u8.p, n, hipMemcpyDeviceToHost));
+    if (stats) stats->seconds_total += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    return RT_OK;
+}
+
+int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_STATE, "rt_debug_bounce: no scene uploaded");
+    if (!io || !io->in_o || !io->in_d || !io->in_key || !io->out_hit || !io->out_t || !io->out_radiance ||
+        !io->out_attenuation || !io->out_o || !io->out_d || !io->out_alive)
+        return fail(ctx, RT_ERR_INVALID, "rt_debug_bounce: NULL array");
+    if (io->n == 0) return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = io->n;
+    // layout of the scratch buffer (floats unless noted)
+    const size_t off_o = 0, off_d = off_o + 3 * n, off_key = off_d + 3 * n, off_hit = off_key + 2 * n, off_t = off_hit + n,
+                 off_rad = off_t + n, off_att = off_rad + 3 * n, off_so = off_att + 3 * n, off_sd = off_so + 3 * n,
+                 off_alive = off_sd + 3 * n, total = off_alive + (n + 3) / 4 + 4;
+    int rc;
+    if ((rc = ensure(ctx, ctx->dbg, total * 4))) return rc;
+    float* base = (float*)ctx->dbg.p;
+    hipStream_t st = ctx->stream;
+    RT_HIP(ctx, hipMemcpyAsync(base + off_o, io->in_o, 3 * n * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(ctx, hipMemcpyAsync(base + off_d, io->in_d, 3 * n * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(ctx, hipMemcpyAsync(base + off_key, io->in_key, 2 * n * 4, hipMemcpyHostToDevice, st));
+    const size_t lds_bytes = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
+    hipLaunchKernelGGL(k_debug_bounce, dim3((unsigned)((n + 255) / 256)), dim3(256), lds_bytes, st, ctx->ds, (uint32_t)n,
+                       (int)io->depth, base + off_o, base + off_d, (const uint32_t*)(base + off_key), (int*)(base + off_hit),
+                       base + off_t, base + off_rad, base + off_att, base + off_so, base + off_sd, (uint8_t*)(base + off_alive));
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(io->out_hit, base + off_hit, n * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(io->out_t, base + off_t, n * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(io->out_radiance, base + off_rad, 3 * n * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(io->out_attenuation, base + off_att, 3 * n * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(io->out_o, base + off_so, 3 * n * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(io->out_d, base + off_sd, 3 * n * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(io->out_alive, base + off_alive, n, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipStreamSynchronize(st));
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,555 @@
+// rt_device.h — gfx950 device functions of the wavefront path tracer: fp32 vector math in the
+// reference's (glam 0.21) operation order, the counter-based RNG, sphere intersection,
+// textures, sky models and all 13 materials.  Citations are to /root/reference/src.
+//
+// Build with -ffp-contract=off: the reference never fuses a*b+c, and with fusion disabled
+// every +,-,*,/ and sqrt below is IEEE-exact, so ray geometry (hit points, scatter
+// directions, branch decisions) is bit-identical to a CPU evaluation of the same formulas;
+// only libm-class functions (sin, cos, acos, atan2, log) may differ in the last ulp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+struct V3 {
+    float x, y, z;
+};
+struct V2 {
+    float x, y;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 splat(float s) { return V3{s, s, s}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 operator/(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ V3 operator+(V3 a, float s) { return V3{a.x + s, a.y + s, a.z + s}; }
+__device__ __forceinline__ V3 operator-(float s, V3 a) { return V3{s - a.x, s - a.y, s - a.z}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+// glam dot3: (x*x' + y*y') + z*z'
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float length_squared(V3 a) { return dot(a, a); }
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
+// glam normalize: v * (1 / length)
+__device__ __forceinline__ V3 normalize(V3 a) {
+    float inv = 1.0f / sqrtf(dot(a, a));
+    return a * inv;
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 lerp3(V3 a, V3 b, float s) { return a + ((b - a) * s); }
+
+#define RT_PI 3.14159265358979323846f
+#define RT_FRAC_1_PI 0.318309886183790671537767526745028724f
+#define RT_FLT_MAX 3.402823466e+38f
+
+__device__ __forceinline__ float powi2(float x) { return x * x; }
+__device__ __forceinline__ float powi5(float x) { // LLVM powi expansion: x * ((x*x)*(x*x))
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    return x * x4;
+}
+// Rust f32::clamp keeps NaN
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {
+    if (x < lo) x = lo;
+    if (x > hi) x = hi;
+    return x;
+}
+// Rust `as u32`: saturating, NaN -> 0
+__device__ __forceinline__ uint32_t sat_u32(float f) {
+    if (!(f == f) || f <= 0.0f) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+__device__ __forceinline__ int32_t sat_i32(float f) {
+    if (!(f == f)) return 0;
+    if (f <= -2147483648.0f) return (int32_t)0x80000000;
+    if (f >= 2147483648.0f) return 0x7FFFFFFF;
+    return (int32_t)f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG (DESIGN.md "RNG"); replaces the thread-local SmallRng of lib.rs:7-9.
+// draw(k0,k1,ctr) = fmix32(fmix32(k0 ^ ctr*0x9E3779B9) + k1); f32 = (u32 >> 8) * 2^-24 exactly
+// as rand's Standard distribution maps a u32 (main.rs:89-90, math.rs:19-21).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ void path_key(uint64_t seed, uint32_t pix, uint32_t samp, uint32_t& k0, uint32_t& k1) {
+    uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
+    uint32_t a = fmix32(pix ^ s_lo);
+    k0 = fmix32(a + samp * 0x9E3779B9u + s_hi);
+    k1 = fmix32((a ^ 0xA511E9B3u) + samp * 0xC2B2AE3Du);
+}
+struct Rng {
+    uint32_t k0, k1, ctr;
+    __device__ __forceinline__ float next() {
+        uint32_t r = fmix32(fmix32(k0 ^ (ctr * 0x9E3779B9u)) + k1);
+        ++ctr;
+        return (float)(r >> 8) * (1.0f / 16777216.0f);
+    }
+};
+__device__ __forceinline__ uint32_t depth_counter_base(int depth) { return (uint32_t)(depth + 1) * 256u; }
+
+// ---------------------------------------------------------------------------------------------
+// math.rs sampling and geometry helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 random_in_unit_sphere(Rng& rng) { // math.rs:17-37
+    for (;;) {
+        float x = rng.next();
+        float y = rng.next();
+        float z = rng.next();
+        V3 v = v3(x, y, z) * (1.0f - -1.0f) + -1.0f;
+        if (length_squared(v) < 1.0f) return v;
+    }
+}
+__device__ __forceinline__ V3 random_on_hemisphere(Rng& rng, V3 n) { // math.rs:43-53
+    V3 v = random_in_unit_sphere(rng);
+    if (!(dot(v, n) > 0.0f)) v = -v;
+    return normalize(v);
+}
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - 2.0f * dot(v, n) * n; } // math.rs:68-70
+__device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat) {             // math.rs:72-77
+    float cos_theta = -fminf(dot(uv, n), 1.0f);
+    V3 r_out_perp = etai_over_etat * (uv + cos_theta * n);
+    V3 r_out_parallel = -sqrtf(fabsf(1.0f - length_squared(r_out_perp))) * n;
+    return r_out_perp + r_out_parallel;
+}
+__device__ __forceinline__ float schlick_fresnel(float u) { return powi5(1.0f - u); } // math.rs:79-81
+__device__ __forceinline__ float reflectance(float cosine, float ref_idx) {           // math.rs:84-88
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * schlick_fresnel(cosine);
+}
+__device__ __forceinline__ float lerpf(float from, float to, float s) { return from + (to - from) * s; } // math.rs:154-156
+__device__ __forceinline__ float offset_axis(float p, float n) { // one lane of math.rs:137-152
+    const float ORIGIN = 1.0f / 32.0f;
+    const float INT_SCALE = 256.0f;
+    const float FLOAT_SCALE = 1.0f / 65536.0f;
+    int32_t of_i = sat_i32(n * INT_SCALE);
+    uint32_t bits = __float_as_uint(p) + (uint32_t)(p < 0.0f ? -of_i : of_i);
+    float p_i = __uint_as_float(bits);
+    return fabsf(p) < ORIGIN ? p + n * FLOAT_SCALE : p_i;
+}
+__device__ __forceinline__ V3 offset_hit_point(V3 p, V3 n) { // math.rs:137-152
+    return v3(offset_axis(p.x, n.x), offset_axis(p.y, n.y), offset_axis(p.z, n.z));
+}
+__device__ __forceinline__ bool near_one(V3 d) { return fabsf(length(d) - 1.0f) < 1e-6f; } // math.rs:13-15
+
+// hitable.rs:65-71 Sphere::get_uv
+__device__ __forceinline__ V2 sphere_get_uv(V3 n) {
+    float theta = acosf(-n.y);
+    float phi = atan2f(-n.z, n.x) + RT_PI;
+    return V2{phi / (2.0f * RT_PI), theta / RT_PI};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed device records (built by rt_scene_upload from RtFlatScene)
+// ---------------------------------------------------------------------------------------------
+struct MatRec { // 48 B
+    uint32_t type, tex0, tex1, pad0;
+    float cr, cg, cb, p0;
+    float p1, p2, p3, pad1;
+};
+struct TexRec { // 48 B
+    uint32_t type, aux;
+    float scale;
+    uint32_t pad0;
+    float c0r, c0g, c0b, pad1;
+    float c1r, c1g, c1b, pad2;
+};
+struct ImgRec { // 16 B
+    uint32_t w, h;
+    uint32_t offset_lo, offset_hi; // offset in texels into the float4 texel pool
+};
+struct DevScene {
+    uint32_t n_spheres;
+    uint32_t n_materials;
+    uint32_t n_textures;
+    uint32_t n_perlin;
+    uint32_t n_images;
+    uint32_t sky_type;
+    uint32_t sky_image;
+    uint32_t pad;
+    const float4* sph_geo;   // (cx, cy, cz, r)
+    const uint32_t* sph_mat;
+    const MatRec* mats;
+    const TexRec* texs;
+    const float4* perlin_vec;   // [n_perlin*256] xyz_
+    const uint8_t* perlin_perm; // [n_perlin*3*256]
+    const ImgRec* imgs;
+    const float4* texels;       // rgb_
+};
+
+// ---------------------------------------------------------------------------------------------
+// texture.rs
+// ---------------------------------------------------------------------------------------------
+__device__ inline float perlin_noise(const DevScene& sc, uint32_t set, V3 p) { // texture.rs:125-146, 93-112
+    const float4* rv = sc.perlin_vec + (size_t)set * 256;
+    const uint8_t* px = sc.perlin_perm + (size_t)set * 768;
+    const uint8_t* py = px + 256;
+    const uint8_t* pz = py + 256;
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    V3 uvw = p - v3(fx, fy, fz);
+    V3 uvw2 = uvw * uvw * (3.0f - 2.0f * uvw); // math.rs:133-135 smooth
+    float u = uvw2.x, v = uvw2.y, w = uvw2.z;
+    uint32_t hx[2] = {px[i & 255], px[(i + 1) & 255]};
+    uint32_t hy[2] = {py[j & 255], py[(j + 1) & 255]};
+    uint32_t hz[2] = {pz[k & 255], pz[(k + 1) & 255]};
+    float accum = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                float4 g = rv[hx[a] ^ hy[b] ^ hz[d]];
+                V3 weight = uvw - v3((float)a, (float)b, (float)d);
+                accum += dot(v3(g.x, g.y, g.z), weight) * (a == 1 ? u : 1.0f - u) * (b == 1 ? v : 1.0f - v) *
+                         (d == 1 ? w : 1.0f - w);
+            }
+    return accum;
+}
+__device__ inline float perlin_turb(const DevScene& sc, uint32_t set, V3 p) { // texture.rs:115-124
+    float accum = 0.0f;
+    float w = 1.0f;
+    for (int it = 0; it < 7; ++it) {
+        accum += w * perlin_noise(sc, set, p);
+        p = p * 2.0f;
+        w *= 0.5f;
+    }
+    return fabsf(accum);
+}
+__device__ inline V3 image_value(const DevScene& sc, uint32_t img, V2 uv, uint32_t& n_fetch) { // texture.rs:183-193
+    ImgRec ir = sc.imgs[img];
+    float u = clampf(uv.x, 0.0f, 1.0f);
+    float v = 1.0f - clampf(uv.y, 0.0f, 1.0f);
+    uint32_t i = min(sat_u32(u * (float)ir.w), ir.w - 1u);
+    uint32_t j = min(sat_u32(v * (float)ir.h), ir.h - 1u);
+    uint64_t off = ((uint64_t)ir.offset_hi << 32) | ir.offset_lo;
+    float4 t = sc.texels[off + (uint64_t)j * ir.w + i];
+    ++n_fetch;
+    return v3(t.x, t.y, t.z);
+}
+// `on` = outward unit normal of the hit sphere, from which rec.uv is derived lazily (hitable.rs:98)
+__device__ inline V3 texture_value(const DevScene& sc, uint32_t tex, V3 on, V3 p, uint32_t& n_fetch) {
+    TexRec tr = sc.texs[tex];
+    switch (tr.type) {
+    case 0: // ConstantTex texture.rs:19-23
+        return v3(tr.c0r, tr.c0g, tr.c0b);
+    case 1: { // CheckerTex texture.rs:40-49
+        float sines = sinf(p.x * 10.0f) * sinf(p.y * 10.0f) * sinf(p.z * 10.0f);
+        return sines < 0.0f ? v3(tr.c0r, tr.c0g, tr.c0b) : v3(tr.c1r, tr.c1g, tr.c1b);
+    }
+    case 2: { // PerlinTex texture.rs:164-168
+        float s = sinf(10.0f * perlin_turb(sc, tr.aux, p) + tr.scale * p.z);
+        return (s + 1.0f) * 0.5f * splat(1.0f);
+    }
+    default: // ImageTex
+        return image_value(sc, tr.aux, sphere_get_uv(on), n_fetch);
+    }
+}
+
+// demo_scene.rs:22-35
+__device__ inline V3 sky_value(const DevScene& sc, V3 d, uint32_t& n_fetch) {
+    if (sc.sky_type == 0) { // sky_color demo_scene.rs:28-31
+        float t = d.y * 0.5f + 0.5f;
+        return lerp3(splat(1.0f), v3(0.5f, 0.7f, 1.0f), t);
+    }
+    if (sc.sky_type == 2) { // tex_sky_color demo_scene.rs:22-26
+        V2 uv = sphere_get_uv(d);
+        V3 c = image_value(sc, sc.sky_image, V2{1.0f - uv.x, uv.y}, n_fetch);
+        return c * c;
+    }
+    return splat(0.0f); // black_sky
+}
+
+// ---------------------------------------------------------------------------------------------
+// pbr.rs helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gtr1(float n_dot_h, float a) { // pbr.rs:72-79
+    if (a >= 1.0f) return RT_FRAC_1_PI;
+    float a2 = a * a;
+    float t = 1.0f + (a2 - 1.0f) * n_dot_h * n_dot_h;
+    return (a2 - 1.0f) / (RT_PI * logf(a2) * t);
+}
+__device__ __forceinline__ float gtr2(float n_dot_h, float a) { // pbr.rs:81-85
+    float a2 = a * a;
+    float t = 1.0f + (a2 - 1.0f) * n_dot_h * n_dot_h;
+    return a2 / (RT_PI * t * t);
+}
+__device__ __forceinline__ float gtr2_aniso(V3 h, float ax, float ay) { // pbr.rs:87-89
+    return 1.0f / (RT_PI * ax * ay * powi2(powi2(h.x / ax) + powi2(h.y / ay) + h.z * h.z));
+}
+__device__ __forceinline__ float smith_geo_ggx(float n_dot_v, float alpha) { // pbr.rs:92-96
+    float a = alpha * alpha;
+    float b = n_dot_v * n_dot_v;
+    return 1.0f / (n_dot_v + sqrtf(a + b - a * b));
+}
+__device__ __forceinline__ float smith_geo_ggx_aniso(V3 v, float ax, float ay) { // pbr.rs:98-100
+    return 1.0f / (v.z + sqrtf(powi2(v.x * ax) + powi2(v.y * ay) + v.z * v.z));
+}
+__device__ __forceinline__ float fresnel_dielectric(float n_dot_i, float n_dot_t, float eta) { // pbr.rs:107-113
+    float rs = (n_dot_i - eta * n_dot_t) / (n_dot_i + eta * n_dot_t);
+    float rp = (eta * n_dot_i - n_dot_t) / (eta * n_dot_i + n_dot_t);
+    return (rs * rs + rp * rp) / 2.0f;
+}
+__device__ __forceinline__ float fresnel_dielectric_2(float n_dot_i, float eta) { // pbr.rs:120-129
+    float n_dot_t_sq = 1.0f - (1.0f - n_dot_i * n_dot_i) / (eta * eta);
+    if (n_dot_t_sq < 0.0f) return 1.0f;
+    return fresnel_dielectric(fabsf(n_dot_i), sqrtf(n_dot_t_sq), eta);
+}
+__device__ __forceinline__ float smith_masking_gtr2_2(V3 v_world, V3 n, float roughness) { // pbr.rs:145-152
+    float alpha = roughness * roughness;
+    float a2 = alpha * alpha;
+    float v2_z_ = dot(v_world, n);
+    float v2_z = v2_z_ * v2_z_;
+    float lambda = (-1.0f + sqrtf(1.0f + a2 * (1.0f - v2_z) / v2_z)) / 2.0f;
+    return 1.0f / (1.0f + lambda);
+}
+// hitable.rs:37-41 HitRecord::world_to_local_with_rot
+__device__ __forceinline__ V3 world_to_local_with_rot(V3 norm, V3 tang0, V3 v, float rot) {
+    V3 tang = cosf(rot) * tang0 - sinf(rot) * cross(norm, tang0);
+    V3 bitang = cross(norm, tang);
+    return v3(dot(v, tang), dot(v, bitang), dot(v, norm));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Closest hit against one sphere (hitable.rs:75-91).  Returns the accepted root in `t_hit`.
+// The caller keeps (t, index) only; the HitRecord fields (hitable.rs:93-99) are derived
+// once for the final hit in shade().
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sphere_root(float4 g, V3 o, V3 d, float a, float t_min, float t_max, float& t_hit) {
+    V3 oc = o - v3(g.x, g.y, g.z);
+    float half_b = dot(oc, d);
+    float c = length_squared(oc) - g.w * g.w;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0f) return false;
+    float sqrtd = sqrtf(discriminant);
+    float root = (-half_b - sqrtd) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || t_max < root) return false;
+    }
+    t_hit = root;
+    return true;
+}
+
+// Result of one bounce for one ray.
+struct Bounce {
+    V3 radiance;    // emitted (hit) or sky (miss) term of this segment, untinted
+    V3 attenuation; // material attenuation when alive
+    V3 o, d;        // scattered ray when alive
+    bool alive;
+};
+
+// main.rs:44-58 for one segment whose closest hit is already known.
+// hit < 0: miss -> sky.  Otherwise rebuild the HitRecord (hitable.rs:93-99) and run
+// emitted + scatter of the material (material.rs, pbr.rs).
+__device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float t, Rng& rng, uint32_t& n_fetch) {
+    Bounce out;
+    out.radiance = splat(0.0f);
+    out.attenuation = splat(1.0f);
+    out.o = splat(0.0f);
+    out.d = splat(0.0f);
+    out.alive = false;
+    if (hit < 0) {
+        out.radiance = sky_value(sc, rd, n_fetch); // main.rs:58
+        return out;
+    }
+    float4 g = sc.sph_geo[hit];
+    V3 p = ro + rd * t;                                 // math.rs:64 Ray::at
+    V3 on = (p - v3(g.x, g.y, g.z)) / g.w;              // hitable.rs:95 outward_normal
+    bool front_face = dot(rd, on) < 0.0f;               // hitable.rs:26
+    V3 n = front_face ? on : -on;                       // hitable.rs:27-31
+    MatRec m = sc.mats[sc.sph_mat[hit]];
+    switch (m.type) {
+    case 0: // Emission material.rs:21-28
+        out.radiance = texture_value(sc, m.tex0, on, p, n_fetch);
+        return out;
+    case 1: { // Diffuse material.rs:35-46
+        V3 sd = n + normalize(random_in_unit_sphere(rng));
+        const float eps = 1.1920929e-7f;
+        if (fabsf(sd.x) < eps && fabsf(sd.y) < eps && fabsf(sd.z) < eps) sd = n; // math.rs:8-11
+        out.o = offset_hit_point(p, n);
+        out.d = normalize(sd);
+        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch);
+        out.alive = true;
+        return out;
+    }
+    case 3: { // Metal material.rs:66-73
+        V3 reflected = reflect(rd, n) + m.p0 * random_in_unit_sphere(rng);
+        out.o = p;
+        out.d = normalize(reflected);
+        out.attenuation = v3(m.cr, m.cg, m.cb);
+        out.alive = dot(reflected, n) > 0.0f;
+        return out;
+    }
+    case 4: { // Dielectric material.rs:79-97
+        float ref_idx = front_face ? 1.0f / m.p0 : m.p0;
+        float cos_theta = -fminf(dot(rd, n), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool cannot_refract = sin_theta * ref_idx > 1.0f;
+        float rnd_num = rng.next();
+        V3 dir = (cannot_refract || reflectance(cos_theta, ref_idx) > rnd_num) ? reflect(rd, n) : refract(rd, n, ref_idx);
+        out.o = p;
+        out.d = normalize(dir);
+        out.alive = true;
+        return out;
+    }
+    case 5: { // Isotropic material.rs:103-113
+        out.o = p;
+        out.d = normalize(random_in_unit_sphere(rng));
+        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch);
+        out.alive = true;
+        return out;
+    }
+    default:
+        break;
+    }
+    // Lambert (material.rs:52-59) and the seven pbr.rs materials share: offset origin + a
+    // uniform hemisphere direction (pbr.rs:19-20 and equivalents).
+    V3 po = offset_hit_point(p, n);
+    V3 dir_o = random_on_hemisphere(rng, n);
+    out.o = po;
+    out.d = dir_o;
+    out.alive = true;
+    float n_dot_i = dot(n, -rd);
+    float n_dot_o = dot(n, dir_o);
+    switch (m.type) {
+    case 2: // Lambert material.rs:56
+        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch) * 2.0f * dot(n, dir_o);
+        break;
+    case 6: { // OrenNayar pbr.rs:21-39
+        float cos_i = fabsf(dot(n, rd));
+        float cos_o = n_dot_o;
+        float sin_i = sqrtf(1.0f - cos_i * cos_i);
+        float sin_o = sqrtf(1.0f - cos_o * cos_o);
+        float max_cos = fmaxf(cos_i * cos_o + sin_i * sin_o, 0.0f);
+        float r2 = m.p0 * m.p0;
+        float a = 1.0f - 0.5f * r2 / (r2 + 0.33f);
+        float b = 0.45f * r2 / (r2 + 0.09f);
+        float sin_alpha, tan_beta;
+        if (cos_i > cos_o) {
+            sin_alpha = sin_o;
+            tan_beta = sin_i / cos_i;
+        } else {
+            sin_alpha = sin_i;
+            tan_beta = sin_o / cos_o;
+        }
+        float w = a + b * max_cos * sin_alpha * tan_beta;
+        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch) * w * 2.0f * cos_o;
+        break;
+    }
+    case 7: { // BurleyDiffuse pbr.rs:54-66
+        V3 h = normalize(dir_o - rd);
+        float h_dot_o = dot(h, dir_o);
+        float fl = schlick_fresnel(n_dot_o);
+        float fv = schlick_fresnel(n_dot_i);
+        float fd90 = 0.5f + 2.0f * h_dot_o * h_dot_o * m.p0;
+        float fd = lerpf(1.0f, fd90, fl) * lerpf(1.0f, fd90, fv);
+        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch) * fd * 2.0f * n_dot_o;
+        break;
+    }
+    case 8: { // RoughPlastic pbr.rs:164-186
+        V3 h = normalize(dir_o - rd);
+        float h_dot_i = dot(h, -rd);
+        float h_dot_o = dot(h, dir_o);
+        float n_dot_h = dot(n, h);
+        V3 kd = texture_value(sc, m.tex1, on, p, n_fetch);
+        V3 ks = texture_value(sc, m.tex0, on, p, n_fetch);
+        float roughness = clampf(m.p0, 0.01f, 1.0f);
+        float eta = m.p1;
+        float f_o = fresnel_dielectric_2(h_dot_o, eta);
+        float dd = gtr2(n_dot_h, roughness);
+        float gg = smith_masking_gtr2_2(-rd, n, roughness) * smith_masking_gtr2_2(dir_o, n, roughness);
+        V3 spec_contrib = ks * (gg * f_o * dd) / (4.0f * n_dot_i * n_dot_o);
+        float f_i = fresnel_dielectric_2(h_dot_i, eta);
+        V3 diff_contrib = kd * (1.0f - f_o) * (1.0f - f_i) * RT_FRAC_1_PI;
+        out.attenuation = (spec_contrib + diff_contrib) * n_dot_o * 2.0f * RT_PI;
+        break;
+    }
+    case 9: { // DisneyDiffuse pbr.rs:202-220
+        V3 h = normalize(dir_o - rd);
+        float h_dot_o = dot(h, dir_o);
+        float fo = schlick_fresnel(n_dot_o);
+        float fi = schlick_fresnel(n_dot_i);
+        float fd90 = 0.5f + 2.0f * h_dot_o * h_dot_o * m.p0;
+        float fd = lerpf(1.0f, fd90, fo) * lerpf(1.0f, fd90, fi);
+        float fss90 = m.p0 * h_dot_o * h_dot_o;
+        float fss_wi = lerpf(1.0f, fss90, fi);
+        float fss_wo = lerpf(1.0f, fss90, fo);
+        float fss = 1.25f * (fss_wi * fss_wo * (1.0f / (n_dot_i + n_dot_o) - 0.5f) + 0.5f);
+        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch) * lerpf(fd, fss, m.p1) * 2.0f * n_dot_o;
+        break;
+    }
+    case 10: { // DisneyMetal pbr.rs:236-275
+        V3 h = normalize(dir_o - rd);
+        float h_dot_o = dot(h, dir_o);
+        float n_dot_h = dot(n, h);
+        V3 albedo = texture_value(sc, m.tex0, on, p, n_fetch);
+        V3 fm = lerp3(albedo, splat(1.0f), schlick_fresnel(h_dot_o));
+        const float alpha_min = 0.0001f;
+        float dm, gm;
+        if (m.p1 > -10.0f) {
+            float aspect = sqrtf(1.0f - 0.9f * m.p1);
+            float ax = fmaxf(m.p0 * m.p0 / aspect, alpha_min);
+            float ay = fmaxf(m.p0 * m.p0 * aspect, alpha_min);
+            float rot = m.p2 * 2.0f * RT_PI;
+            V3 tang = normalize(cross(v3(0.0f, 1.0f, 0.0f), on)); // hitable.rs:96
+            V3 h_local = world_to_local_with_rot(n, tang, h, rot);
+            dm = gtr2_aniso(h_local, ax, ay);
+            V3 i_local = world_to_local_with_rot(n, tang, -rd, rot);
+            V3 o_local = world_to_local_with_rot(n, tang, dir_o, rot);
+            gm = smith_geo_ggx_aniso(i_local, ax, ay) * smith_geo_ggx_aniso(o_local, ax, ay);
+        } else {
+            float r2 = fmaxf(m.p0 * m.p0, alpha_min);
+            dm = gtr2(n_dot_h, r2);
+            gm = smith_geo_ggx(n_dot_i, r2) * smith_geo_ggx(n_dot_o, r2);
+        }
+        V3 metal_w = fm * dm * gm;
+        out.attenuation = metal_w * n_dot_o * 2.0f * RT_PI;
+        break;
+    }
+    case 11: { // DisneySheen pbr.rs:290-305
+        V3 h = normalize(dir_o - rd);
+        float h_dot_o = dot(h, dir_o);
+        V3 albedo = texture_value(sc, m.tex0, on, p, n_fetch);
+        float luminance = dot(v3(0.3f, 0.6f, 0.1f), albedo);
+        V3 c_tint = luminance > 0.0f ? albedo / luminance : splat(1.0f);
+        V3 c_sheen = lerp3(splat(1.0f), c_tint, m.p0);
+        V3 f_sheen = c_sheen * schlick_fresnel(h_dot_o);
+        out.attenuation = f_sheen * n_dot_o * 2.0f * RT_PI;
+        break;
+    }
+    case 12: { // DisneyClearcoat pbr.rs:318-332
+        V3 h = normalize(dir_o - rd);
+        float h_dot_o = dot(h, dir_o);
+        float n_dot_h = dot(n, h);
+        float fc = lerpf(0.4f, 1.0f, schlick_fresnel(h_dot_o));
+        float dc = gtr1(n_dot_h, lerpf(0.1f, 0.001f, m.p0));
+        float gc = smith_geo_ggx(n_dot_i, 0.25f) * smith_geo_ggx(n_dot_o, 0.25f);
+        float cc = 0.25f * fc * dc * gc;
+        out.attenuation = splat(cc) * n_dot_o * 2.0f * RT_PI;
+        break;
+    }
+    default: // unknown tag: absorb
+        out.alive = false;
+        break;
+    }
+    return out;
+}
+
+} // namespace rt

@@ -1,0 +1,291 @@
+// rt_kernels.h — the wavefront (ray-queue) kernels for gfx950.
+//
+//   k_gen_primary  : main.rs:86-94 + camera.rs:40-46, one lane per (pixel, sample) of a slice
+//   k_trace_shade  : main.rs:44-58 for every live ray of one depth: closest hit against the
+//                    LDS-staged sphere list (hitable.rs:75-102,117-132), emitted + scatter
+//                    (material.rs, pbr.rs, texture.rs), wave64 ballot compaction of survivors
+//   k_resolve      : main.rs:95-98 sample sum in sample order
+//   k_finalize     : main.rs:98-105,127 /spp, gamma 2, *255.99 as u8, vertical flip
+//
+// Ray queue layout in HBM ("SoA of float4", 48 B per ray, 16 B per lane per load so that one
+// wave instruction moves 1 KiB contiguous):
+//   qa[i] = (o.x, o.y, o.z, slot)   slot = path slot of the slice = s_local * npix + pixel_local
+//   qb[i] = (d.x, d.y, d.z, k0)     (k0,k1) = per-path RNG key
+//   qc[i] = (T.x, T.y, T.z, k1)     T = path throughput
+// The queue is split into `nq` sub-queues (shards) of capacity `cap` rays; a workgroup reads
+// shard q = blockIdx % nq and appends survivors to shard q of the output queue, so that the
+// append counter is sharded nq ways (one device-scope atomic per wave per chunk).
+#pragma once
+#include "rt_device.h"
+
+namespace rt {
+
+struct Queue {
+    float4* a;
+    float4* b;
+    float4* c;
+};
+
+struct GenParams {
+    float cam_origin[3], cam_horizontal[3], cam_vertical[3], cam_llc[3];
+    uint32_t nx, ny;
+    uint32_t npix;        // pixels of this shard (rows_local * nx)
+    uint32_t n_rays;      // npix * s_count
+    uint32_t s0;          // first sample index of the slice
+    uint32_t shard_band, shard_count, shard_id;
+    uint32_t nq, cap;
+    uint32_t seed_lo, seed_hi;
+};
+
+__device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t band, uint32_t count, uint32_t id) {
+    if (count <= 1) return lj;
+    return ((lj / band) * count + id) * band + (lj % band);
+}
+
+// One lane per primary ray of the slice.  idx = s_local * npix + pixel_local, so consecutive
+// lanes are consecutive pixels of a row (coherent first hit).
+__global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q, uint32_t* __restrict__ counts) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    // block 0 publishes the per-shard ray counts of depth 0 (closed form of the mapping below)
+    if (blockIdx.x == 0 && threadIdx.x < gp.nq) {
+        const uint32_t nchunks = (gp.n_rays + 255u) / 256u;
+        const uint32_t sq = threadIdx.x;
+        uint32_t nc = sq < nchunks ? (nchunks - sq + gp.nq - 1u) / gp.nq : 0u;
+        uint32_t cnt = nc * 256u;
+        if (nc && ((nchunks - 1u) % gp.nq) == sq) cnt -= nchunks * 256u - gp.n_rays;
+        counts[sq] = cnt;
+    }
+    if (idx >= gp.n_rays) return;
+    const uint32_t s_local = idx / gp.npix;
+    const uint32_t pl = idx - s_local * gp.npix;
+    const uint32_t lj = pl / gp.nx;
+    const uint32_t i = pl - lj * gp.nx;
+    const uint32_t j = local_row_to_image_row(lj, gp.shard_band, gp.shard_count, gp.shard_id);
+    const uint32_t samp = gp.s0 + s_local;
+    Rng rng;
+    path_key(((uint64_t)gp.seed_hi << 32) | gp.seed_lo, j * gp.nx + i, samp, rng.k0, rng.k1);
+    rng.ctr = 0;
+    // main.rs:89-90
+    float u = ((float)i + rng.next()) / (float)gp.nx;
+    float v = ((float)j + rng.next()) / (float)gp.ny;
+    // camera.rs:40-46
+    V3 origin = v3(gp.cam_origin[0], gp.cam_origin[1], gp.cam_origin[2]);
+    V3 H = v3(gp.cam_horizontal[0], gp.cam_horizontal[1], gp.cam_horizontal[2]);
+    V3 Vv = v3(gp.cam_vertical[0], gp.cam_vertical[1], gp.cam_vertical[2]);
+    V3 llc = v3(gp.cam_llc[0], gp.cam_llc[1], gp.cam_llc[2]);
+    V3 d = normalize(llc + u * H + v * Vv - origin);
+    const uint32_t chunk = idx >> 8;
+    const uint32_t sq = chunk % gp.nq;
+    const size_t pos = (size_t)sq * gp.cap + (size_t)(chunk / gp.nq) * 256u + (idx & 255u);
+    q.a[pos] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(idx));
+    q.b[pos] = make_float4(d.x, d.y, d.z, __uint_as_float(rng.k0));
+    q.c[pos] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.k1));
+}
+
+// LDS tile of the sphere list: (cx, cy, cz, r) as float4, read by every lane at the same
+// address (broadcast, conflict-free).
+#define RT_SPHERE_TILE 2048u
+
+// Closest hit over the whole list, HitableList::hit order and acceptance rule
+// (hitable.rs:117-132: t_max shrinks to the closest so far; a root equal to t_max is accepted).
+__device__ __forceinline__ void closest_hit_tile(const float4* s_geo, uint32_t n, uint32_t base, V3 o, V3 d, float a,
+                                                 float& tbest, int& hit) {
+    for (uint32_t s = 0; s < n; ++s) {
+        float th;
+        if (sphere_root(s_geo[s], o, d, a, 1e-3f, tbest, th)) {
+            tbest = th;
+            hit = (int)(base + s);
+        }
+    }
+}
+
+struct TraceParams {
+    uint32_t nq, cap;
+    int depth, max_depth;
+};
+
+__global__ __launch_bounds__(256) void k_trace_shade(DevScene sc, Queue qin, Queue qout,
+                                                     const uint32_t* __restrict__ in_counts,
+                                                     uint32_t* __restrict__ out_counts, float* __restrict__ rad,
+                                                     TraceParams tp, unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* s_geo = reinterpret_cast<float4*>(smem);
+    const uint32_t q = blockIdx.x % tp.nq;
+    const uint32_t bq = blockIdx.x / tp.nq;
+    const uint32_t nbq = gridDim.x / tp.nq;
+    const uint32_t count = in_counts[q];
+    if (bq * 256u >= count) return; // block-uniform: nothing queued for this workgroup
+    const uint32_t n_sph = sc.n_spheres;
+    const bool single_tile = n_sph <= RT_SPHERE_TILE;
+    if (single_tile) {
+        for (uint32_t i = threadIdx.x; i < n_sph; i += 256u) s_geo[i] = sc.sph_geo[i];
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_fetch = 0, n_bad = 0;
+    const size_t qbase = (size_t)q * tp.cap;
+    for (uint32_t base = bq * 256u; base < count; base += nbq * 256u) {
+        const uint32_t i = base + threadIdx.x;
+        const bool active = i < count;
+        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 1.f, 0.f), rc = ra;
+        if (active) {
+            ra = qin.a[qbase + i];
+            rb = qin.b[qbase + i];
+            rc = qin.c[qbase + i];
+        }
+        const V3 o = v3(ra.x, ra.y, ra.z), d = v3(rb.x, rb.y, rb.z), T = v3(rc.x, rc.y, rc.z);
+        const uint32_t slot = __float_as_uint(ra.w);
+        // closest hit: main.rs:44 world.hit(&r, 1e-3, f32::MAX, &mut rec)
+        float tbest = RT_FLT_MAX;
+        int hit = -1;
+        const float a = length_squared(d); // hitable.rs:77
+        if (single_tile) {
+            closest_hit_tile(s_geo, n_sph, 0u, o, d, a, tbest, hit);
+        } else {
+            for (uint32_t t0 = 0; t0 < n_sph; t0 += RT_SPHERE_TILE) {
+                const uint32_t n = min(RT_SPHERE_TILE, n_sph - t0);
+                __syncthreads();
+                for (uint32_t k = threadIdx.x; k < n; k += 256u) s_geo[k] = sc.sph_geo[t0 + k];
+                __syncthreads();
+                closest_hit_tile(s_geo, n, t0, o, d, a, tbest, hit);
+            }
+        }
+        bool alive = false;
+        V3 L = splat(0.0f);
+        Bounce bo;
+        bo.o = bo.d = bo.attenuation = splat(0.0f);
+        uint32_t k0 = __float_as_uint(rb.w), k1 = __float_as_uint(rc.w);
+        if (active) {
+            if (!near_one(d)) { // main.rs:39 assert!: the reference panics; the path is dropped
+                ++n_bad;
+            } else {
+                Rng rng{k0, k1, depth_counter_base(tp.depth)};
+                bo = shade(sc, o, d, hit, tbest, rng, n_fetch);
+                if (bo.alive) {
+                    // survivors of the last traced depth return 0 at main.rs:40-42
+                    alive = tp.depth < tp.max_depth;
+                } else {
+                    L = T * bo.radiance; // L = T_n * (emitted | sky)
+                }
+            }
+            if (!alive) {
+                float* r = rad + (size_t)slot * 3u;
+                r[0] = L.x, r[1] = L.y, r[2] = L.z;
+            }
+        }
+        // wave64 compaction: ballot + prefix popcount, one atomic per wave to claim queue slots
+        const unsigned long long mask = __ballot(alive);
+        if (mask) {
+            const uint32_t n_alive = (uint32_t)__popcll(mask);
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&out_counts[q], n_alive);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (alive) {
+                const uint32_t rank =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const size_t pos = qbase + wbase + rank;
+                const V3 Tn = T * bo.attenuation;
+                qout.a[pos] = make_float4(bo.o.x, bo.o.y, bo.o.z, __uint_as_float(slot));
+                qout.b[pos] = make_float4(bo.d.x, bo.d.y, bo.d.z, __uint_as_float(k0));
+                qout.c[pos] = make_float4(Tn.x, Tn.y, Tn.z, __uint_as_float(k1));
+            }
+        }
+    }
+    // rare-event counters: one atomic per wave, only when nonzero
+    for (int off = 32; off > 0; off >>= 1) {
+        n_fetch += __shfl_down(n_fetch, off);
+        n_bad += __shfl_down(n_bad, off);
+    }
+    if (lane == 0) {
+        if (n_fetch) atomicAdd(&stats[0], (unsigned long long)n_fetch);
+        if (n_bad) atomicAdd(&stats[1], (unsigned long long)n_bad);
+    }
+}
+
+// Sums the slice's samples of each pixel in sample order (main.rs:95-97) onto the running sum.
+__global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ rad, float* __restrict__ acc, uint32_t npix,
+                                                 uint32_t s_count) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= npix) return;
+    float r = acc[3 * (size_t)p], g = acc[3 * (size_t)p + 1], b = acc[3 * (size_t)p + 2];
+    for (uint32_t s = 0; s < s_count; ++s) {
+        const float* src = rad + ((size_t)s * npix + p) * 3u;
+        r += src[0];
+        g += src[1];
+        b += src[2];
+    }
+    acc[3 * (size_t)p] = r, acc[3 * (size_t)p + 1] = g, acc[3 * (size_t)p + 2] = b;
+}
+
+// main.rs:98-105,127.  out_f32: linear mean (before gamma), local row order; out_u8: gamma 2,
+// *255.99 saturating cast, rows flipped.  sqrtf is the correctly rounded value of powf(x, 0.5).
+__global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ acc, float* __restrict__ out_f32,
+                                                  uint8_t* __restrict__ out_u8, uint32_t nx, uint32_t rows, uint32_t spp) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= nx * rows) return;
+    const float fs = (float)spp;
+    float c[3] = {acc[3 * (size_t)p] / fs, acc[3 * (size_t)p + 1] / fs, acc[3 * (size_t)p + 2] / fs};
+    if (out_f32) {
+        out_f32[3 * (size_t)p] = c[0], out_f32[3 * (size_t)p + 1] = c[1], out_f32[3 * (size_t)p + 2] = c[2];
+    }
+    if (out_u8) {
+        const uint32_t lj = p / nx, i = p - lj * nx;
+        const size_t dst = ((size_t)(rows - 1u - lj) * nx + i) * 3u;
+        for (int k = 0; k < 3; ++k) {
+            float g = sqrtf(c[k]) * 255.99f;
+            uint32_t u = (g == g && g > 0.0f) ? (g >= 255.0f ? 255u : (uint32_t)g) : 0u;
+            out_u8[dst + k] = (uint8_t)u;
+        }
+    }
+}
+
+// Sums the per-shard counters of every depth into 64-bit totals (ray statistics).
+__global__ void k_accum_counts(const uint32_t* __restrict__ counts, uint32_t nq, uint32_t n_depths,
+                               unsigned long long* __restrict__ totals) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_depths) return;
+    unsigned long long s = 0;
+    for (uint32_t k = 0; k < nq; ++k) s += counts[(size_t)d * nq + k];
+    totals[d] += s;
+}
+
+// Test hook: one bounce for caller-given rays, no compaction (rt_debug_bounce).
+__global__ __launch_bounds__(256) void k_debug_bounce(DevScene sc, uint32_t n, int depth, const float* __restrict__ in_o,
+                                                      const float* __restrict__ in_d, const uint32_t* __restrict__ in_key,
+                                                      int* __restrict__ out_hit, float* __restrict__ out_t,
+                                                      float* __restrict__ out_rad, float* __restrict__ out_att,
+                                                      float* __restrict__ out_o, float* __restrict__ out_d,
+                                                      uint8_t* __restrict__ out_alive) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* s_geo = reinterpret_cast<float4*>(smem);
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool active = i < n;
+    V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
+    if (active) {
+        o = v3(in_o[3 * i], in_o[3 * i + 1], in_o[3 * i + 2]);
+        d = v3(in_d[3 * i], in_d[3 * i + 1], in_d[3 * i + 2]);
+    }
+    float tbest = RT_FLT_MAX;
+    int hit = -1;
+    const float a = length_squared(d);
+    for (uint32_t t0 = 0; t0 < sc.n_spheres; t0 += RT_SPHERE_TILE) {
+        const uint32_t nn = min(RT_SPHERE_TILE, sc.n_spheres - t0);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nn; k += 256u) s_geo[k] = sc.sph_geo[t0 + k];
+        __syncthreads();
+        closest_hit_tile(s_geo, nn, t0, o, d, a, tbest, hit);
+    }
+    if (!active) return;
+    uint32_t n_fetch = 0;
+    Rng rng{in_key[2 * i], in_key[2 * i + 1], depth_counter_base(depth)};
+    Bounce bo = shade(sc, o, d, hit, tbest, rng, n_fetch);
+    out_hit[i] = hit;
+    out_t[i] = hit >= 0 ? tbest : 0.0f;
+    out_rad[3 * i] = bo.radiance.x, out_rad[3 * i + 1] = bo.radiance.y, out_rad[3 * i + 2] = bo.radiance.z;
+    out_att[3 * i] = bo.attenuation.x, out_att[3 * i + 1] = bo.attenuation.y, out_att[3 * i + 2] = bo.attenuation.z;
+    out_o[3 * i] = bo.o.x, out_o[3 * i + 1] = bo.o.y, out_o[3 * i + 2] = bo.o.z;
+    out_d[3 * i] = bo.d.x, out_d[3 * i + 1] = bo.d.y, out_d[3 * i + 2] = bo.d.z;
+    out_alive[i] = bo.alive ? 1 : 0;
+}
+
+} // namespace rt

@@ -1,0 +1,175 @@
+// demo_scene.cpp — host-side mirror of the reference scene builders that feed the accelerated
+// path (demo_scene.rs:37-86 sphere_scene, demo_scene.rs:229-244 test_sphere) plus the two
+// build-authored scenes BASELINE.json configs 4 and 5 call for.  The other three reference
+// scenes (simple_light_scene, cornell_box, final_scene) need rect/box/medium primitives and are
+// outside the accelerated path.
+#include "rtow.hpp"
+
+#include <cstdio>
+
+namespace rtow {
+
+std::shared_ptr<const DecodedImage> load_ppm(const std::string& path) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return nullptr;
+    auto img = std::make_shared<DecodedImage>();
+    char magic[3] = {0, 0, 0};
+    int w = 0, h = 0, maxv = 0;
+    auto next_int = [&](int& v) {
+        int c = std::fgetc(f);
+        for (;;) {
+            while (c == ' ' || c == '\n' || c == '\r' || c == '\t') c = std::fgetc(f);
+            if (c == '#') {
+                while (c != '\n' && c != EOF) c = std::fgetc(f);
+                continue;
+            }
+            break;
+        }
+        if (c < '0' || c > '9') return false;
+        v = 0;
+        while (c >= '0' && c <= '9') v = v * 10 + (c - '0'), c = std::fgetc(f);
+        return true; // the single whitespace after the token has been consumed
+    };
+    bool ok = std::fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && magic[1] == '6' && next_int(w) && next_int(h) &&
+              next_int(maxv) && w > 0 && h > 0 && maxv == 255;
+    if (ok) {
+        std::vector<unsigned char> raw((size_t)w * h * 3);
+        ok = std::fread(raw.data(), 1, raw.size(), f) == raw.size();
+        if (ok) {
+            img->w = (uint32_t)w, img->h = (uint32_t)h;
+            img->rgb.resize(raw.size());
+            for (size_t i = 0; i < raw.size(); ++i) img->rgb[i] = (float)raw[i] / 255.0f; // to_rgb32f
+        }
+    }
+    std::fclose(f);
+    return ok ? img : nullptr;
+}
+
+static std::pair<HitableList, Camera> build_bvh(HitableList& world, Camera cam) { // demo_scene.rs:223-227
+    HitableList out;
+    out.push_back(BvhNode::new_(world, 0, world.size()));
+    return {out, cam};
+}
+
+// demo_scene.rs:37-86 — "random-spheres": 4 fixed spheres + 23x23 small ones, no rejection
+// around the big spheres (unlike the book), 533 spheres in total.
+std::pair<HitableList, Camera> sphere_scene(float aspect_ratio) {
+    SKY_COLOR_set(SkyFn::sky_color); // :38
+    auto perlin = PerlinTex::new_(4.0f);                   // :41 (first consumer of the thread RNG)
+    auto earth_map = ImageTex::new_("res/earthmap.jpg");   // :42
+    auto material_ground = std::make_shared<Diffuse>(perlin);
+    auto material_1 = std::make_shared<Emission>(earth_map);
+    auto material_2 = std::make_shared<Dielectric>(1.5f);
+    auto material_3 = std::make_shared<Metal>(vec3a(0.8f, 0.6f, 0.2f), 0.0f);
+    HitableList world = {
+        std::make_shared<Sphere>(vec3a(1.0f, -1000.0f, -1.0f), 1000.0f, material_ground, "Ground"),
+        std::make_shared<Sphere>(vec3a(0.0f, 1.0f, 3.0f), 1.0f, material_1, "Sphere_1"),
+        std::make_shared<Sphere>(vec3a(-4.0f, 1.0f, 0.0f), 1.0f, material_2, "Sphere_2"),
+        std::make_shared<Sphere>(vec3a(4.0f, 1.0f, 0.0f), 1.0f, material_3, "Sphere_3"),
+    };
+    SmallRng rng = SmallRng::seed_from_u64(95); // :56
+    for (int a = -11; a <= 11; ++a) {
+        for (int b = -11; b <= 11; ++b) {
+            float choose_mat = rng.gen_f32();
+            float cx = (float)a + 0.9f * rng.gen_f32();
+            float cz = (float)b + 0.9f * rng.gen_f32();
+            Vec3A center = vec3a(cx, 0.2f, cz);
+            MaterialPtr mat;
+            if (choose_mat < 0.8f) {
+                float ax = rng.gen_f32(), ay = rng.gen_f32(), az = rng.gen_f32();
+                float bx = rng.gen_f32(), by = rng.gen_f32(), bz = rng.gen_f32();
+                Vec3A col = vec3a(ax, ay, az) * vec3a(bx, by, bz);
+                mat = std::make_shared<Diffuse>(std::make_shared<ConstantTex>(col));
+            } else if (choose_mat < 0.95f) {
+                float ax = rng.gen_f32(), ay = rng.gen_f32(), az = rng.gen_f32();
+                Vec3A albedo = vec3a(ax, ay, az) * 0.5f + 0.5f;
+                float fuzz = rng.gen_f32();
+                mat = std::make_shared<Metal>(albedo, fuzz);
+            } else {
+                mat = material_2;
+            }
+            world.push_back(std::make_shared<Sphere>(center, 0.2f, mat, "Sphere " + std::to_string(a) + ", " + std::to_string(b)));
+        }
+    }
+    Camera cam = Camera::new_(vec3a(13.0f, 2.0f, 3.0f), vec3a(0.0f, 0.0f, 0.0f), vec3a(0.0f, 1.0f, 0.0f), 20.0f, aspect_ratio);
+    return build_bvh(world, cam); // :85
+}
+
+// demo_scene.rs:229-244 — two Lambert spheres, gradient sky, no BVH.
+std::pair<HitableList, Camera> test_sphere(float aspect_ratio) {
+    SKY_COLOR_set(SkyFn::sky_color);
+    auto ground = std::make_shared<Lambert>(std::make_shared<ConstantTex>(vec3a(0.5f, 0.5f, 0.5f)));
+    HitableList world = {
+        std::make_shared<Sphere>(vec3a(0.0f, -100.5f, -1.0f), 100.0f, ground, "Ground"),
+        std::make_shared<Sphere>(vec3a(0.0f, 0.0f, -1.0f), 0.5f, ground, "Test"),
+    };
+    Camera cam = Camera::new_(vec3a(0.0f, 0.0f, 0.0f), vec3a(0.0f, 0.0f, -1.0f), vec3a(0.0f, 1.0f, 0.0f), 90.0f, aspect_ratio);
+    return {world, cam};
+}
+
+// BASELINE.json config 4: earthmap-textured sphere under the newport_loft environment sky.
+// Built from reference constructors only: Diffuse{ImageTex} as final_scene does
+// (demo_scene.rs:160-162), Emission{earth_map} as sphere_scene does (:45,51), sky =
+// tex_sky_color over ENV_TEX (demo_scene.rs:22-26, main.rs:63).
+std::pair<HitableList, Camera> earth_env_scene(float aspect_ratio) {
+    ENV_TEX_set(ImageTex::new_("res/newport_loft.jpg")); // main.rs:63
+    SKY_COLOR_set(SkyFn::tex_sky_color);
+    auto earth_map = ImageTex::new_("res/earthmap.jpg");
+    auto ground = std::make_shared<Diffuse>(CheckerTex::new_(vec3a(0.2f, 0.3f, 0.1f), vec3a(0.9f, 0.9f, 0.9f))); // demo_scene.rs:40
+    HitableList world = {
+        std::make_shared<Sphere>(vec3a(0.0f, -1000.0f, 0.0f), 1000.0f, ground, "Ground"),
+        std::make_shared<Sphere>(vec3a(0.0f, 2.0f, 0.0f), 2.0f, std::make_shared<Diffuse>(earth_map), "EarthSphere"),
+        std::make_shared<Sphere>(vec3a(-4.5f, 1.5f, 1.5f), 1.5f, std::make_shared<Dielectric>(1.5f), "Glass"),
+        std::make_shared<Sphere>(vec3a(4.5f, 1.5f, -1.0f), 1.5f, std::make_shared<Metal>(vec3a(0.9f, 0.9f, 0.9f), 0.0f), "Mirror"),
+        std::make_shared<Sphere>(vec3a(1.5f, 0.6f, 4.0f), 0.6f, std::make_shared<Emission>(earth_map), "EarthLamp"),
+    };
+    Camera cam = Camera::new_(vec3a(13.0f, 3.0f, 6.0f), vec3a(0.0f, 1.5f, 0.0f), vec3a(0.0f, 1.0f, 0.0f), 30.0f, aspect_ratio);
+    return build_bvh(world, cam);
+}
+
+// BASELINE.json config 5: GGX metal/rough sweep, 25 x 20 = 500 spheres + ground = 501 spheres,
+// every pbr.rs material, parameters on a deterministic grid (no RNG, so the scene is seed-free).
+std::pair<HitableList, Camera> pbr_sweep_scene(float aspect_ratio) {
+    SKY_COLOR_set(SkyFn::sky_color);
+    auto white = std::make_shared<ConstantTex>(vec3a(1.0f, 1.0f, 1.0f));
+    HitableList world = {
+        std::make_shared<Sphere>(vec3a(0.0f, -1000.0f, 0.0f), 1000.0f,
+                                 std::make_shared<Diffuse>(std::make_shared<ConstantTex>(vec3a(0.5f, 0.5f, 0.5f))), "Ground"),
+    };
+    for (int b = 0; b < 20; ++b) {
+        for (int a = 0; a < 25; ++a) {
+            float fa = (float)a / 24.0f; // sweep along x
+            int sub = b % 4;
+            float fs = (float)sub / 3.0f;
+            Vec3A col = vec3a(0.25f + 0.7f * fa, 0.9f - 0.6f * fs, 0.3f + 0.6f * (1.0f - fa));
+            auto tex = std::make_shared<ConstantTex>(col);
+            MaterialPtr mat;
+            switch (b / 4) {
+            case 0: // anisotropic GGX metal: roughness along x, anisotropy + rotation along z
+                mat = std::make_shared<DisneyMetal>(tex, 0.05f + 0.95f * fa, fs, 0.125f * (float)sub);
+                break;
+            case 1: // rough dielectric-coated plastic
+                mat = std::make_shared<RoughPlastic>(white, tex, 0.01f + 0.99f * fa, 1.3f + 0.2f * fs);
+                break;
+            case 2: // clearcoat lobe only
+                mat = std::make_shared<DisneyClearcoat>(fa);
+                break;
+            case 3: // the diffuse family
+                if (sub == 0) mat = std::make_shared<OrenNayar>(tex, fa);
+                else if (sub == 1) mat = std::make_shared<BurleyDiffuse>(tex, fa);
+                else if (sub == 2) mat = std::make_shared<DisneyDiffuse>(tex, fa, 0.5f);
+                else mat = std::make_shared<DisneySheen>(tex, fa);
+                break;
+            default: // isotropic-looking metal (anisotropic = 0 still takes the aniso branch, pbr.rs:247)
+                mat = std::make_shared<DisneyMetal>(tex, 0.05f + 0.95f * fa, 0.0f, 0.0f);
+                break;
+            }
+            Vec3A c = vec3a(((float)a - 12.0f) * 0.9f, 0.35f, ((float)b - 9.5f) * 0.9f);
+            world.push_back(std::make_shared<Sphere>(c, 0.35f, mat, "Sweep " + std::to_string(a) + ", " + std::to_string(b)));
+        }
+    }
+    Camera cam = Camera::new_(vec3a(0.0f, 16.0f, 24.0f), vec3a(0.0f, 0.0f, 0.0f), vec3a(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio);
+    return build_bvh(world, cam);
+}
+
+} // namespace rtow

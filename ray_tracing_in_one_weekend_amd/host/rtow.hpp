@@ -1,0 +1,530 @@
+// rtow.hpp — host-side C++ mirror of the reference's scene-construction API (the drop-in
+// surface).  Same names, argument meaning and defaults as the Rust types:
+//
+//   Camera::new_(lookfrom, lookat, vup, vfov_deg, aspect)      camera.rs:14-39
+//   Sphere{c, r, mat, name}                                    hitable.rs:57-62
+//   HitableList = vector<shared_ptr<Hitable>>                  hitable.rs:114
+//   BvhNode::new_(objects, start, end)                         hitable.rs:177-221
+//   Emission{emit} Diffuse{albedo} Lambert{albedo} Metal{albedo,fuzz} Dielectric{ior}
+//   Isotropic{albedo}                                          material.rs
+//   OrenNayar BurleyDiffuse RoughPlastic DisneyDiffuse DisneyMetal DisneySheen DisneyClearcoat  pbr.rs
+//   ConstantTex{col} CheckerTex::new_(odd,even) PerlinTex::new_(scale) ImageTex::new_(path)  texture.rs
+//   SKY_COLOR (lib.rs:11), RNG (lib.rs:7-9), ENV_TEX (demo_scene.rs:19)
+//
+// The one addition a Rust host would also need (trait objects give no introspection,
+// SURVEY.md §8(b)): every Hitable/Material/Texture has `flatten(FlatSceneBuilder&)`, which
+// emits the structure-of-arrays RtFlatScene that crosses the C-ABI (include/rtow_mi355x.h).
+// The GPU replaces BVH traversal by its own closest-hit search, so BvhNode flattens to the
+// spheres it holds.
+//
+// Rust `new` is spelled `new_` (C++ keyword).  This header is product code: it must not
+// include anything from oracle/.
+#pragma once
+#include "../../include/rtow_mi355x.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace rtow {
+
+// ---- glam::Vec3A (the subset the constructors use) ------------------------------------------
+struct Vec3A {
+    float x = 0, y = 0, z = 0;
+    static Vec3A ZERO() { return Vec3A{0, 0, 0}; }
+    static Vec3A ONE() { return Vec3A{1, 1, 1}; }
+    Vec3A operator+(Vec3A b) const { return {x + b.x, y + b.y, z + b.z}; }
+    Vec3A operator-(Vec3A b) const { return {x - b.x, y - b.y, z - b.z}; }
+    Vec3A operator*(Vec3A b) const { return {x * b.x, y * b.y, z * b.z}; }
+    Vec3A operator*(float s) const { return {x * s, y * s, z * s}; }
+    Vec3A operator/(float s) const { return {x / s, y / s, z / s}; }
+    Vec3A operator+(float s) const { return {x + s, y + s, z + s}; }
+    float dot(Vec3A b) const { return (x * b.x + y * b.y) + z * b.z; }
+    float length() const { return std::sqrt(dot(*this)); }
+    Vec3A normalize() const { return *this * (1.0f / length()); }
+    Vec3A cross(Vec3A b) const { return {y * b.z - z * b.y, z * b.x - x * b.z, x * b.y - y * b.x}; }
+};
+inline Vec3A operator*(float s, Vec3A v) { return {s * v.x, s * v.y, s * v.z}; }
+inline Vec3A vec3a(float x, float y, float z) { return Vec3A{x, y, z}; }
+
+// ---- rand 0.8.5 SmallRng (xoshiro256++, rand_core PCG32 seed expansion) -----------------------
+class SmallRng {
+  public:
+    static SmallRng seed_from_u64(uint64_t state) {
+        SmallRng r;
+        uint32_t w[8];
+        for (int i = 0; i < 8; ++i) {
+            state = state * 6364136223846793005ull + 11634580027462260723ull;
+            uint32_t xs = (uint32_t)(((state >> 18) ^ state) >> 27);
+            uint32_t rot = (uint32_t)(state >> 59);
+            w[i] = (xs >> rot) | (xs << ((32u - rot) & 31u));
+        }
+        for (int i = 0; i < 4; ++i) r.s_[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+        if (!(r.s_[0] | r.s_[1] | r.s_[2] | r.s_[3])) { // zero seed -> SplitMix64(0), as xoshiro's from_seed does
+            uint64_t z = 0;
+            for (int i = 0; i < 4; ++i) {
+                z += 0x9e3779b97f4a7c15ull;
+                uint64_t v = z;
+                v = (v ^ (v >> 30)) * 0xbf58476d1ce4e5b9ull;
+                v = (v ^ (v >> 27)) * 0x94d049bb133111ebull;
+                r.s_[i] = v ^ (v >> 31);
+            }
+        }
+        return r;
+    }
+    uint64_t next_u64() {
+        uint64_t result = rotl(s_[0] + s_[3], 23) + s_[0];
+        uint64_t t = s_[1] << 17;
+        s_[2] ^= s_[0], s_[3] ^= s_[1], s_[1] ^= s_[2], s_[0] ^= s_[3], s_[2] ^= t;
+        s_[3] = rotl(s_[3], 45);
+        return result;
+    }
+    uint32_t next_u32() { return (uint32_t)(next_u64() >> 32); }
+    float gen_f32() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); } // rng.gen::<f32>()
+    uint32_t gen_range_u32(uint32_t high_excl) {                               // gen_range(0..high) for u32
+        uint32_t zone = (high_excl << __builtin_clz(high_excl)) - 1u;
+        for (;;) {
+            uint64_t m = (uint64_t)next_u32() * high_excl;
+            if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+        }
+    }
+    uint64_t gen_range_usize(uint64_t high_excl) { // gen_range(0..high) for usize
+        uint64_t zone = (high_excl << __builtin_clzll(high_excl)) - 1ull;
+        for (;;) {
+            unsigned __int128 m = (unsigned __int128)next_u64() * high_excl;
+            if ((uint64_t)m <= zone) return (uint64_t)(m >> 64);
+        }
+    }
+    template <class T>
+    void shuffle(std::vector<T>& v) { // SliceRandom::shuffle
+        for (size_t i = v.size() - 1; i >= 1; --i) std::swap(v[i], v[gen_range_u32((uint32_t)(i + 1))]);
+    }
+
+  private:
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t s_[4] = {0, 0, 0, 0};
+};
+
+// lib.rs:7-9 — thread-local RNG seeded 1995 (Perlin tables, BVH axes draw from it)
+inline SmallRng& RNG() {
+    thread_local SmallRng rng = SmallRng::seed_from_u64(1995);
+    return rng;
+}
+inline void RNG_reseed(uint64_t seed) { RNG() = SmallRng::seed_from_u64(seed); }
+
+// ---- flat-scene builder -------------------------------------------------------------------------
+class Texture;
+class Material;
+class ImageTex;
+
+class FlatSceneBuilder {
+  public:
+    // interned by object identity so that shared Arc<dyn _> stay shared
+    uint32_t intern_texture(const Texture* t);
+    uint32_t intern_material(const Material* m);
+    uint32_t add_image(const ImageTex* img);
+    uint32_t add_perlin(const float* vec768, const uint16_t* perm768) {
+        perlin_vec.insert(perlin_vec.end(), vec768, vec768 + 768);
+        perlin_perm.insert(perlin_perm.end(), perm768, perm768 + 768);
+        return (uint32_t)(perlin_vec.size() / 768 - 1);
+    }
+    uint32_t push_texture(uint8_t type, Vec3A c0, Vec3A c1, float scale, uint32_t aux) {
+        tex_type.push_back(type);
+        push3(tex_color0, c0), push3(tex_color1, c1);
+        tex_scale.push_back(scale), tex_aux.push_back(aux);
+        return (uint32_t)tex_type.size() - 1;
+    }
+    uint32_t push_material(uint8_t type, Vec3A color, float p0, float p1, float p2, float p3, uint32_t t0, uint32_t t1) {
+        mat_type.push_back(type);
+        push3(mat_color, color);
+        mat_p0.push_back(p0), mat_p1.push_back(p1), mat_p2.push_back(p2), mat_p3.push_back(p3);
+        mat_tex0.push_back(t0), mat_tex1.push_back(t1);
+        return (uint32_t)mat_type.size() - 1;
+    }
+    void push_sphere(Vec3A c, float r, uint32_t mat, const std::string& name) {
+        sph_cx.push_back(c.x), sph_cy.push_back(c.y), sph_cz.push_back(c.z), sph_r.push_back(r), sph_mat.push_back(mat);
+        sph_name.push_back(name);
+    }
+    RtFlatScene view() const {
+        RtFlatScene s;
+        std::memset(&s, 0, sizeof(s));
+        s.n_spheres = (uint32_t)sph_r.size();
+        s.sph_cx = sph_cx.data(), s.sph_cy = sph_cy.data(), s.sph_cz = sph_cz.data(), s.sph_r = sph_r.data();
+        s.sph_mat = sph_mat.data();
+        s.n_materials = (uint32_t)mat_type.size();
+        s.mat_type = mat_type.data(), s.mat_color = mat_color.data();
+        s.mat_p0 = mat_p0.data(), s.mat_p1 = mat_p1.data(), s.mat_p2 = mat_p2.data(), s.mat_p3 = mat_p3.data();
+        s.mat_tex0 = mat_tex0.data(), s.mat_tex1 = mat_tex1.data();
+        s.n_textures = (uint32_t)tex_type.size();
+        s.tex_type = tex_type.data(), s.tex_color0 = tex_color0.data(), s.tex_color1 = tex_color1.data();
+        s.tex_scale = tex_scale.data(), s.tex_aux = tex_aux.data();
+        s.n_perlin = (uint32_t)(perlin_vec.size() / 768);
+        s.perlin_vec = perlin_vec.data(), s.perlin_perm = perlin_perm.data();
+        s.n_images = (uint32_t)img_w.size();
+        s.img_w = img_w.data(), s.img_h = img_h.data(), s.img_offset = img_offset.data();
+        s.texels = texels.data(), s.n_texel_floats = texels.size();
+        s.sky_type = sky_type, s.sky_image = sky_image;
+        return s;
+    }
+
+    std::vector<float> sph_cx, sph_cy, sph_cz, sph_r;
+    std::vector<uint32_t> sph_mat;
+    std::vector<std::string> sph_name;
+    std::vector<uint8_t> mat_type;
+    std::vector<float> mat_color, mat_p0, mat_p1, mat_p2, mat_p3;
+    std::vector<uint32_t> mat_tex0, mat_tex1;
+    std::vector<uint8_t> tex_type;
+    std::vector<float> tex_color0, tex_color1, tex_scale;
+    std::vector<uint32_t> tex_aux;
+    std::vector<float> perlin_vec;
+    std::vector<uint16_t> perlin_perm;
+    std::vector<uint32_t> img_w, img_h;
+    std::vector<uint64_t> img_offset;
+    std::vector<float> texels;
+    uint32_t sky_type = RT_SKY_GRADIENT, sky_image = 0;
+
+  private:
+    static void push3(std::vector<float>& v, Vec3A c) { v.push_back(c.x), v.push_back(c.y), v.push_back(c.z); }
+    std::unordered_map<const void*, uint32_t> tex_ids_, mat_ids_, img_ids_;
+};
+
+// ---- texture.rs ------------------------------------------------------------------------------------
+class Texture {
+  public:
+    virtual ~Texture() = default;
+    virtual uint32_t flatten(FlatSceneBuilder& b) const = 0; // returns the texture index
+};
+using TexturePtr = std::shared_ptr<const Texture>;
+
+struct ConstantTex : Texture { // texture.rs:15-17
+    Vec3A col;
+    explicit ConstantTex(Vec3A c) : col(c) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override { return b.push_texture(RT_TEX_CONSTANT, col, Vec3A{}, 0.0f, 0); }
+};
+class CheckerTex : public Texture { // texture.rs:25-37; odd/even are ConstantTex by construction
+  public:
+    static std::shared_ptr<CheckerTex> new_(Vec3A odd_col, Vec3A even_col) {
+        return std::shared_ptr<CheckerTex>(new CheckerTex(odd_col, even_col));
+    }
+    uint32_t flatten(FlatSceneBuilder& b) const override { return b.push_texture(RT_TEX_CHECKER, odd_, even_, 0.0f, 0); }
+
+  private:
+    CheckerTex(Vec3A o, Vec3A e) : odd_(o), even_(e) {}
+    Vec3A odd_, even_;
+};
+class PerlinTex : public Texture { // texture.rs:53-91,153-161: tables drawn from the thread RNG
+  public:
+    static std::shared_ptr<PerlinTex> new_(float scale) { return std::shared_ptr<PerlinTex>(new PerlinTex(scale)); }
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_texture(RT_TEX_PERLIN, Vec3A{}, Vec3A{}, scale_, b.add_perlin(vec_, perm_));
+    }
+    const float* rand_vec() const { return vec_; }
+    const uint16_t* perm() const { return perm_; }
+
+  private:
+    explicit PerlinTex(float scale) : scale_(scale) {
+        SmallRng& rng = RNG();
+        for (int i = 0; i < 256; ++i) { // vec3a_random_range(-1., 1.)
+            float x = rng.gen_f32(), y = rng.gen_f32(), z = rng.gen_f32();
+            Vec3A v = vec3a(x, y, z) * (1.0f - -1.0f) + -1.0f;
+            vec_[3 * i] = v.x, vec_[3 * i + 1] = v.y, vec_[3 * i + 2] = v.z;
+        }
+        std::vector<uint16_t> p(256);
+        for (int i = 0; i < 256; ++i) p[(size_t)i] = (uint16_t)i;
+        for (int k = 0; k < 3; ++k) { // perm_x, perm_y, perm_z: successive shuffles of the same vector
+            rng.shuffle(p);
+            std::memcpy(perm_ + 256 * k, p.data(), 256 * sizeof(uint16_t));
+        }
+    }
+    float scale_;
+    float vec_[768];
+    uint16_t perm_[768];
+};
+
+// Decoded images registered by path (JPEG decode happens in the embedding host; see
+// INTEGRATION.md).  ImageTex::new_(path) resolves against this registry first, then falls
+// back to binary PPM (P6) files.
+struct DecodedImage {
+    uint32_t w = 0, h = 0;
+    std::vector<float> rgb; // Rgb<f32> = u8 / 255 (texture.rs:177 to_rgb32f)
+};
+inline std::map<std::string, std::shared_ptr<const DecodedImage>>& image_registry() {
+    static std::map<std::string, std::shared_ptr<const DecodedImage>> reg;
+    return reg;
+}
+inline void register_image(const std::string& path, uint32_t w, uint32_t h, const float* rgb) {
+    auto img = std::make_shared<DecodedImage>();
+    img->w = w, img->h = h;
+    img->rgb.assign(rgb, rgb + (size_t)w * h * 3);
+    image_registry()[path] = img;
+}
+std::shared_ptr<const DecodedImage> load_ppm(const std::string& path); // demo_scene.cpp
+
+class ImageTex : public Texture { // texture.rs:170-181
+  public:
+    static std::shared_ptr<ImageTex> new_(const std::string& path) {
+        auto it = image_registry().find(path);
+        std::shared_ptr<const DecodedImage> img = it != image_registry().end() ? it->second : load_ppm(path);
+        if (!img) throw std::runtime_error("ImageTex::new: cannot open " + path);
+        return std::shared_ptr<ImageTex>(new ImageTex(img));
+    }
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_texture(RT_TEX_IMAGE, Vec3A{}, Vec3A{}, 0.0f, b.add_image(this));
+    }
+    const DecodedImage& img() const { return *img_; }
+
+  private:
+    explicit ImageTex(std::shared_ptr<const DecodedImage> i) : img_(std::move(i)) {}
+    std::shared_ptr<const DecodedImage> img_;
+};
+
+// ---- material.rs / pbr.rs ------------------------------------------------------------------------
+class Material {
+  public:
+    virtual ~Material() = default;
+    virtual uint32_t flatten(FlatSceneBuilder& b) const = 0; // returns the material index
+};
+using MaterialPtr = std::shared_ptr<const Material>;
+
+#define RTOW_TEX_MATERIAL(Name, TAG, FIELD)                                                          \
+    struct Name : Material {                                                                         \
+        TexturePtr FIELD;                                                                            \
+        explicit Name(TexturePtr t) : FIELD(std::move(t)) {}                                         \
+        uint32_t flatten(FlatSceneBuilder& b) const override {                                       \
+            return b.push_material(TAG, Vec3A{}, 0, 0, 0, 0, b.intern_texture(FIELD.get()), RT_NO_TEX); \
+        }                                                                                            \
+    }
+RTOW_TEX_MATERIAL(Emission, RT_MAT_EMISSION, emit);    // material.rs:17-19
+RTOW_TEX_MATERIAL(Diffuse, RT_MAT_DIFFUSE, albedo);    // material.rs:31-33
+RTOW_TEX_MATERIAL(Lambert, RT_MAT_LAMBERT, albedo);    // material.rs:48-50
+RTOW_TEX_MATERIAL(Isotropic, RT_MAT_ISOTROPIC, albedo);// material.rs:99-101
+#undef RTOW_TEX_MATERIAL
+
+struct Metal : Material { // material.rs:61-64
+    Vec3A albedo;
+    float fuzz;
+    Metal(Vec3A a, float f) : albedo(a), fuzz(f) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_material(RT_MAT_METAL, albedo, fuzz, 0, 0, 0, RT_NO_TEX, RT_NO_TEX);
+    }
+};
+struct Dielectric : Material { // material.rs:75-77
+    float ior;
+    explicit Dielectric(float i) : ior(i) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_material(RT_MAT_DIELECTRIC, Vec3A{}, ior, 0, 0, 0, RT_NO_TEX, RT_NO_TEX);
+    }
+};
+struct OrenNayar : Material { // pbr.rs:12-15
+    TexturePtr albedo;
+    float roughness;
+    OrenNayar(TexturePtr a, float r) : albedo(std::move(a)), roughness(r) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_material(RT_MAT_OREN_NAYAR, Vec3A{}, roughness, 0, 0, 0, b.intern_texture(albedo.get()), RT_NO_TEX);
+    }
+};
+struct BurleyDiffuse : Material { // pbr.rs:45-48
+    TexturePtr albedo;
+    float roughness;
+    BurleyDiffuse(TexturePtr a, float r) : albedo(std::move(a)), roughness(r) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_material(RT_MAT_BURLEY_DIFFUSE, Vec3A{}, roughness, 0, 0, 0, b.intern_texture(albedo.get()), RT_NO_TEX);
+    }
+};
+struct RoughPlastic : Material { // pbr.rs:153-158
+    TexturePtr spec_color, diff_color;
+    float roughness, eta;
+    RoughPlastic(TexturePtr s, TexturePtr d, float r, float e)
+        : spec_color(std::move(s)), diff_color(std::move(d)), roughness(r), eta(e) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_material(RT_MAT_ROUGH_PLASTIC, Vec3A{}, roughness, eta, 0, 0, b.intern_texture(spec_color.get()),
+                               b.intern_texture(diff_color.get()));
+    }
+};
+struct DisneyDiffuse : Material { // pbr.rs:192-196
+    TexturePtr albedo;
+    float roughness, subsurface;
+    DisneyDiffuse(TexturePtr a, float r, float s) : albedo(std::move(a)), roughness(r), subsurface(s) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_material(RT_MAT_DISNEY_DIFFUSE, Vec3A{}, roughness, subsurface, 0, 0, b.intern_texture(albedo.get()),
+                               RT_NO_TEX);
+    }
+};
+struct DisneyMetal : Material { // pbr.rs:224-229
+    TexturePtr albedo;
+    float roughness, anisotropic, rot;
+    DisneyMetal(TexturePtr a, float r, float an, float ro) : albedo(std::move(a)), roughness(r), anisotropic(an), rot(ro) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_material(RT_MAT_DISNEY_METAL, Vec3A{}, roughness, anisotropic, rot, 0, b.intern_texture(albedo.get()),
+                               RT_NO_TEX);
+    }
+};
+struct DisneySheen : Material { // pbr.rs:281-284
+    TexturePtr albedo;
+    float tint;
+    DisneySheen(TexturePtr a, float t) : albedo(std::move(a)), tint(t) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_material(RT_MAT_DISNEY_SHEEN, Vec3A{}, tint, 0, 0, 0, b.intern_texture(albedo.get()), RT_NO_TEX);
+    }
+};
+struct DisneyClearcoat : Material { // pbr.rs:310-312
+    float clearcoat_gloss;
+    explicit DisneyClearcoat(float g) : clearcoat_gloss(g) {}
+    uint32_t flatten(FlatSceneBuilder& b) const override {
+        return b.push_material(RT_MAT_DISNEY_CLEARCOAT, Vec3A{}, clearcoat_gloss, 0, 0, 0, RT_NO_TEX, RT_NO_TEX);
+    }
+};
+
+inline uint32_t FlatSceneBuilder::intern_texture(const Texture* t) {
+    if (!t) throw std::runtime_error("flatten: null texture");
+    auto it = tex_ids_.find(t);
+    if (it != tex_ids_.end()) return it->second;
+    uint32_t id = t->flatten(*this);
+    tex_ids_[t] = id;
+    return id;
+}
+inline uint32_t FlatSceneBuilder::intern_material(const Material* m) {
+    if (!m) throw std::runtime_error("flatten: null material");
+    auto it = mat_ids_.find(m);
+    if (it != mat_ids_.end()) return it->second;
+    uint32_t id = m->flatten(*this);
+    mat_ids_[m] = id;
+    return id;
+}
+inline uint32_t FlatSceneBuilder::add_image(const ImageTex* t) {
+    const DecodedImage* key = &t->img();
+    auto it = img_ids_.find(key);
+    if (it != img_ids_.end()) return it->second;
+    uint32_t id = (uint32_t)img_w.size();
+    img_w.push_back(key->w), img_h.push_back(key->h), img_offset.push_back(texels.size());
+    texels.insert(texels.end(), key->rgb.begin(), key->rgb.end());
+    img_ids_[key] = id;
+    return id;
+}
+
+// ---- hitable.rs --------------------------------------------------------------------------------------
+class Hitable {
+  public:
+    virtual ~Hitable() = default;
+    virtual void flatten(FlatSceneBuilder& b) const = 0;
+    virtual std::string memo() const = 0; // hitable.rs:53
+};
+using HitablePtr = std::shared_ptr<const Hitable>;
+using HitableList = std::vector<HitablePtr>; // hitable.rs:114
+
+struct Sphere : Hitable { // hitable.rs:57-62
+    Vec3A c;
+    float r;
+    MaterialPtr mat;
+    std::string name;
+    Sphere(Vec3A c_, float r_, MaterialPtr m, std::string n) : c(c_), r(r_), mat(std::move(m)), name(std::move(n)) {}
+    void flatten(FlatSceneBuilder& b) const override { b.push_sphere(c, r, b.intern_material(mat.get()), name); }
+    std::string memo() const override { return name; }
+};
+
+// hitable.rs:158-221.  The accelerated path does its own closest-hit search, so the mirror
+// keeps the primitives of [start, end) in construction order and replays only the RNG side
+// effect of the reference constructor (one gen_range(0..3) per node, hitable.rs:182-184).
+class BvhNode : public Hitable {
+  public:
+    static std::shared_ptr<BvhNode> new_(HitableList& objects, size_t start, size_t end) {
+        if (end <= start || end > objects.size()) throw std::runtime_error("BvhNode::new: empty span (unimplemented!() in the reference)");
+        draw_axes(end - start);
+        auto n = std::shared_ptr<BvhNode>(new BvhNode());
+        n->items_.assign(objects.begin() + (long)start, objects.begin() + (long)end);
+        return n;
+    }
+    void flatten(FlatSceneBuilder& b) const override {
+        for (auto& h : items_) h->flatten(b);
+    }
+    std::string memo() const override { return "BvhNode"; }
+
+  private:
+    static void draw_axes(size_t span) {
+        (void)RNG().gen_range_usize(3);
+        if (span > 2) {
+            draw_axes(span / 2);
+            draw_axes(span - span / 2);
+        }
+    }
+    HitableList items_;
+};
+
+// ---- lib.rs:11 SKY_COLOR, demo_scene.rs:19 ENV_TEX ------------------------------------------------------
+enum class SkyFn { sky_color, black_sky, tex_sky_color }; // demo_scene.rs:22-35
+struct SkyState {
+    SkyFn fn = SkyFn::sky_color;
+    bool set = false;
+    std::shared_ptr<const ImageTex> env_tex; // ENV_TEX
+};
+inline SkyState& SKY_COLOR() {
+    static SkyState s;
+    return s;
+}
+// OnceCell::set panics when called twice; a library cannot, so the last call wins.
+inline void SKY_COLOR_set(SkyFn fn) { SKY_COLOR().fn = fn, SKY_COLOR().set = true; }
+inline void ENV_TEX_set(std::shared_ptr<const ImageTex> t) { SKY_COLOR().env_tex = std::move(t); }
+
+// ---- camera.rs --------------------------------------------------------------------------------------------
+class Camera {
+  public:
+    static Camera new_(Vec3A lookfrom, Vec3A lookat, Vec3A vup, float vfov, float aspect_ratio) { // camera.rs:14-39
+        Camera c;
+        c.origin = lookfrom;
+        const float RADS_PER_DEG = 3.14159265358979323846f / 180.0f;
+        float theta = vfov * RADS_PER_DEG;
+        float viewport_height = std::tan(theta / 2.0f) * 2.0f;
+        float viewport_width = viewport_height * aspect_ratio;
+        Vec3A w = (lookfrom - lookat).normalize();
+        Vec3A u = vup.cross(w).normalize();
+        Vec3A v = w.cross(u);
+        c.horizontal = viewport_width * u;
+        c.vertical = viewport_height * v;
+        c.lower_left_corner = c.origin - c.horizontal / 2.0f - c.vertical / 2.0f - w;
+        return c;
+    }
+    // the accessor the private fields need (SURVEY.md §8(b) "Obstacle to flattening")
+    RtCamera flatten() const {
+        RtCamera r;
+        const Vec3A* src[4] = {&origin, &horizontal, &vertical, &lower_left_corner};
+        float* dst[4] = {r.origin, r.horizontal, r.vertical, r.lower_left_corner};
+        for (int k = 0; k < 4; ++k) dst[k][0] = src[k]->x, dst[k][1] = src[k]->y, dst[k][2] = src[k]->z;
+        return r;
+    }
+
+  private:
+    Vec3A origin, horizontal, vertical, lower_left_corner;
+};
+
+// Flattens a world + the global sky state into `b`.
+inline void flatten_world(const HitableList& world, FlatSceneBuilder& b) {
+    for (auto& h : world) h->flatten(b);
+    const SkyState& sky = SKY_COLOR();
+    switch (sky.fn) {
+    case SkyFn::sky_color: b.sky_type = RT_SKY_GRADIENT; break;
+    case SkyFn::black_sky: b.sky_type = RT_SKY_BLACK; break;
+    case SkyFn::tex_sky_color:
+        if (!sky.env_tex) throw std::runtime_error("tex_sky_color: ENV_TEX not set (ENV_TEX.get().unwrap() panics in the reference)");
+        b.sky_type = RT_SKY_ENV;
+        b.sky_image = b.add_image(sky.env_tex.get());
+        break;
+    }
+}
+
+// ---- demo_scene.rs ---------------------------------------------------------------------------------------------
+using SceneFn = std::pair<HitableList, Camera> (*)(float aspect_ratio);
+std::pair<HitableList, Camera> sphere_scene(float aspect_ratio); // demo_scene.rs:37-86  "random-spheres"
+std::pair<HitableList, Camera> test_sphere(float aspect_ratio);  // demo_scene.rs:229-244
+// Build-authored scenes from reference constructors (BASELINE.json configs 4 and 5; the
+// reference ships no scene for them).
+std::pair<HitableList, Camera> earth_env_scene(float aspect_ratio);
+std::pair<HitableList, Camera> pbr_sweep_scene(float aspect_ratio);
+
+} // namespace rtow

@@ -1,0 +1,31 @@
+import numpy as np
+
+
+def display(img):
+    """gamma-2, [0,1]-clamped display values (main.rs:99 before quantisation); NaN -> 0."""
+    x = np.nan_to_num(np.asarray(img, dtype=np.float64), nan=0.0, posinf=1.0, neginf=0.0)
+    return np.sqrt(np.clip(x, 0.0, 1.0))
+
+
+def rmse_display(a, b):
+    d = display(a) - display(b)
+    return float(np.sqrt(np.mean(d * d)))
+
+
+def rays_on_scene(n, seed, center=(0.0, 0.5, 0.0), radius=12.0):
+    """Unit-direction rays starting on a sphere around the scene pointing roughly inwards, plus
+    rays starting just above the ground; keys are arbitrary."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v[:, 1] = np.abs(v[:, 1]) * 0.6 + 0.02
+    o = (np.asarray(center) + radius * v).astype(np.float32)
+    tgt = rng.uniform(-6, 6, size=(n, 3))
+    tgt[:, 1] = rng.uniform(-0.2, 1.5, size=n)
+    d = tgt - o
+    d = d.astype(np.float32)
+    # normalise in float32 the glam way: v * (1/len)
+    ln = np.sqrt(((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)
+    d = (d * (np.float32(1.0) / ln)[:, None]).astype(np.float32)
+    keys = rng.integers(0, 2**32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+    return o, d, keys

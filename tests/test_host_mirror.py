@@ -1,0 +1,104 @@
+"""Host-side C++ mirror of the reference constructors (librtow_host.so) against the oracle's
+independent restatement of demo_scene.rs / texture.rs / camera.rs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+F = C.POINTER(C.c_float)
+
+
+def test_sphere_scene_layout_matches_oracle_restatement(rt, orc):
+    lib = orc.load()
+    s = rt.Scene.build("sphere_scene", 16 / 9)
+    a = s.arrays()
+    assert len(a["sph_r"]) == 533  # 4 + 23*23, no rejection around the big spheres (demo_scene.rs:58-77)
+    assert [s.sphere_name(i) for i in range(4)] == ["Ground", "Sphere_1", "Sphere_2", "Sphere_3"]
+    assert s.sphere_name(4) == "Sphere -11, -11"
+    assert a["sph_r"][:4].tolist() == [1000.0, 1.0, 1.0, 1.0] and np.all(a["sph_r"][4:] == np.float32(0.2))
+    lay = np.zeros(529 * 8, np.float32)
+    assert lib.orc_sphere_scene_layout(95, lay.ctypes.data_as(F)) == 529
+    lay = lay.reshape(529, 8)
+    assert np.array_equal(a["sph_cx"][4:], lay[:, 0]) and np.array_equal(a["sph_cz"][4:], lay[:, 2])
+    assert np.all(a["sph_cy"][4:] == np.float32(0.2))
+    mt = a["mat_type"][a["sph_mat"][4:]]
+    kinds = lay[:, 3].astype(int)
+    assert np.array_equal(mt == rt._ffi.MAT_DIFFUSE, kinds == 0)
+    assert np.array_equal(mt == rt._ffi.MAT_METAL, kinds == 1)
+    assert np.array_equal(mt == rt._ffi.MAT_DIELECTRIC, kinds == 2)
+    # colours: Diffuse -> ConstantTex colour, Metal -> albedo + fuzz
+    for i in range(529):
+        m = a["sph_mat"][4 + i]
+        if kinds[i] == 0:
+            t = a["mat_tex0"][m]
+            assert a["tex_type"][t] == rt._ffi.TEX_CONSTANT
+            assert np.array_equal(a["tex_color0"][3 * t:3 * t + 3], lay[i, 4:7])
+        elif kinds[i] == 1:
+            assert np.array_equal(a["mat_color"][3 * m:3 * m + 3], lay[i, 4:7]) and a["mat_p0"][m] == lay[i, 7]
+    # the shared Dielectric Arc stays one material (demo_scene.rs:46,52,73)
+    glass = {int(a["sph_mat"][4 + i]) for i in range(529) if kinds[i] == 2}
+    assert glass == {int(a["sph_mat"][2])}
+    assert a["sky_type"] == rt._ffi.SKY_GRADIENT
+
+
+def test_perlin_tables_follow_thread_rng_seed_1995(rt, orc):
+    lib = orc.load()
+    rt._ffi.load_host_library().rth_rng_reseed(1995)
+    s = rt.Scene.build("sphere_scene", 16 / 9)
+    a = s.arrays()
+    vec = np.zeros(768, np.float32)
+    perm = np.zeros(768, np.uint16)
+    lib.orc_perlin_tables(1995, 1, vec.ctypes.data_as(F), perm.ctypes.data_as(C.POINTER(C.c_uint16)))
+    assert np.array_equal(a["perlin_vec"], vec) and np.array_equal(a["perlin_perm"], perm)
+    for k in range(3):
+        assert sorted(perm[256 * k:256 * (k + 1)].tolist()) == list(range(256))
+    assert np.all(np.abs(vec) <= 1.0)
+
+
+def test_camera_matches_oracle(rt, orc):
+    lib = orc.load()
+    s = rt.Scene.build("sphere_scene", 400 / 225)
+    cam = rt.RtCamera()
+    f = lambda v: np.asarray(v, np.float32).ctypes.data_as(F)
+    lib.orc_camera_new(f([13, 2, 3]), f([0, 0, 0]), f([0, 1, 0]), 20.0, C.c_float(400 / 225), C.byref(cam))
+    for name in ("origin", "horizontal", "vertical", "lower_left_corner"):
+        assert list(getattr(cam, name)) == list(getattr(s.camera, name)), name
+
+
+def test_test_sphere_scene(rt):
+    s = rt.Scene.build("test_sphere", 2.0)
+    a = s.arrays()
+    assert len(a["sph_r"]) == 2 and a["mat_type"].tolist() == [rt._ffi.MAT_LAMBERT]  # shared `ground` Arc
+    assert a["sph_cy"].tolist() == [-100.5, 0.0] and a["sph_r"].tolist() == [100.0, 0.5]
+    assert list(s.camera.lower_left_corner) == [-2.0, -1.0, -1.0]
+
+
+def test_build_authored_scenes(rt):
+    e = rt.Scene.build("earth_env_scene", 16 / 9)
+    assert e.flat.sky_type == rt._ffi.SKY_ENV and e.flat.n_images == 2 and e.flat.n_spheres == 5
+    p = rt.Scene.build("pbr_sweep_scene", 16 / 9)
+    a = p.arrays()
+    assert p.flat.n_spheres == 501
+    assert set(a["mat_type"].tolist()) >= {rt._ffi.MAT_DISNEY_METAL, rt._ffi.MAT_ROUGH_PLASTIC, rt._ffi.MAT_DISNEY_CLEARCOAT,
+                                            rt._ffi.MAT_OREN_NAYAR, rt._ffi.MAT_BURLEY_DIFFUSE, rt._ffi.MAT_DISNEY_DIFFUSE,
+                                            rt._ffi.MAT_DISNEY_SHEEN}
+
+
+def test_piecewise_construction_and_errors(rt):
+    s = rt.Scene.new()
+    t = s.constant_tex((0.1, 0.2, 0.3))
+    m = s.material(rt._ffi.MAT_DIFFUSE, tex0=t)
+    s.sphere((0, 0, -1), 0.5, m, "a")
+    s.sphere((0, 1, -1), 0.25, m, "b")
+    s.set_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 90, 2.0)
+    s.finish()
+    assert s.flat.n_spheres == 2 and s.flat.n_materials == 1 and s.flat.n_textures == 1
+    with pytest.raises(rt.RtError):
+        rt.Scene.build("cornell_box", 1.0)  # rect/box/medium scenes are outside the accelerated path
+    s2 = rt.Scene.new()
+    with pytest.raises(rt.RtError):
+        s2.material(rt._ffi.MAT_DIFFUSE)  # Diffuse needs an albedo texture
+    with pytest.raises(rt.RtError):
+        s2.image_tex("res/does_not_exist.jpg")  # image::open(..).unwrap() panics in the reference
+    with pytest.raises(rt.RtError):
+        s2.finish()  # no camera
