@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X wavefront path tracer.
+
+Metric (BASELINE.json): Mray/s (primary + secondary) on demo_scene.rs `sphere_scene`
+("random-spheres", 533 spheres) at 1920x1080, 256 spp, max depth 50 — config 2.
+
+A "step" is one full render of the frame: every pixel x every sample through the wavefront
+kernels (k_gen_primary -> (max_depth+1) x k_trace_shade -> k_resolve per slice, k_finalize),
+framebuffer resident in HBM.  With N > 1 ranks (one process per GPU, torch.distributed, backend
+nccl == RCCL over xGMI) the image rows are sharded in interleaved bands of 8 rows and each
+step ends with the all_gather of the band buffers.  Scaling is WEAK: the per-GPU path count is
+held at config 2's 530,841,600 by rendering spp = 256*N of the same frame, so every rank traces
+(1080/N rows) x 1920 x 256*N samples.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) including
+  "roofline":     k_trace_shade algorithmic HBM bytes / its device time (HIP events on its stream)
+  "cpu_baseline": the CPU oracle in reference (stream) order, all host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def cpu_baseline(rt, scene, nx, ny, max_depth, budget_s=15.0):
+    """Times the oracle (kind "port": C++ restatement of the reference, stream RNG order, BVH,
+    one worker per host core like threadpool's default) on a bounded sample of the workload:
+    the same frame at reduced spp (Mray/s does not depend on spp)."""
+    from oracle import binding as orc
+    cores = os.cpu_count() or 1
+    opts = orc.options(rng_mode=orc.RNG_STREAM, estimator=orc.EST_RECURSIVE, accel=orc.ACCEL_BVH,
+                       n_threads=cores, bvh_seed=1995, bvh_skip_perlin=1)
+    probe = rt.make_params(nx, ny, 1, max_depth=max_depth, seed=95)
+    t0 = time.time()
+    _, _, st = orc.render(scene.flat_ptr, scene.camera, probe, opts)
+    dt = max(time.time() - t0, 1e-6)
+    spp = int(max(1, min(64, budget_s / dt)))
+    p = rt.make_params(nx, ny, spp, max_depth=max_depth, seed=95)
+    t0 = time.time()
+    _, _, st = orc.render(scene.flat_ptr, scene.camera, p, opts)
+    dt = max(time.time() - t0, 1e-6)
+    return {"value": round(st.n_rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": f"sphere_scene {nx}x{ny}, {spp} spp, max_depth {max_depth}, {st.n_rays} rays in {dt:.1f} s "
+                      f"(oracle stream mode: per-column xoshiro256++, recursive estimator, BVH)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nx", type=int, default=1920)
+    ap.add_argument("--ny", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256, help="samples per pixel PER GPU (weak scaling)")
+    ap.add_argument("--max-depth", type=int, default=50)
+    ap.add_argument("--spp-slice", type=int, default=0)
+    ap.add_argument("--band", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import ray_tracing_in_one_weekend_amd as rt
+    from ray_tracing_in_one_weekend_amd import shard
+
+    rt.register_default_images()
+    nx, ny = args.nx, args.ny
+    scene = rt.Scene.build("sphere_scene", nx / ny)
+    renderer = rt.Renderer(local_rank)  # raises if librtow_mi355x.so is missing
+    renderer.upload(scene)
+    spp_total = args.spp * world
+    params = rt.make_params(nx, ny, spp_total, max_depth=args.max_depth, seed=95, shard_band=args.band,
+                            shard_count=world, shard_id=rank, spp_slice=args.spp_slice)
+    rows = renderer.shard_rows(params)
+    local = torch.zeros((rows, nx, 3), dtype=torch.float32, device="cuda")
+    # a dedicated non-default stream: the library's launches, its HIP events and the RCCL gather are
+    # all ordered on it (stream handle 0 would make the library fall back to its own stream)
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+
+    def step(want_stats):
+        st = renderer.render_device(scene.camera, params, local.data_ptr(), stream=stream, want_stats=want_stats)
+        if world > 1:
+            full = shard.gather_framebuffer(local, ny, args.band)  # RCCL all_gather + de-interleave
+        else:
+            full = local
+        return st, full
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        st, full = step(True)  # reading the counters synchronises; the counters are part of the metric
+        stats.append(st)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    rays_local = sum(s.n_rays for s in stats)
+    t = torch.tensor([elapsed, float(rays_local), sum(s.seconds_trace for s in stats),
+                      float(sum(s.bytes_trace_algorithmic for s in stats))], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, rays_total = tmax[0].item(), tsum[1].item()
+    else:
+        elapsed_max, rays_total = elapsed, float(rays_local)
+
+    if rank == 0:
+        s0 = stats[-1]
+        trace_s = sum(s.seconds_trace for s in stats)
+        trace_bytes = sum(s.bytes_trace_algorithmic for s in stats)
+        launches = sum(s.n_trace_launches for s in stats)
+        achieved = trace_bytes / max(trace_s, 1e-12) / 1e9
+        out = {
+            "metric": "Mray/s (primary+secondary) at 1920x1080/256spp",
+            "value": round(rays_total / elapsed_max / 1e6, 3),
+            "unit": "Mray/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / max(args.steps, 1) * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"demo_scene.rs sphere_scene (random-spheres, 533 spheres) {nx}x{ny}, "
+                                   f"{args.spp} spp per GPU ({spp_total} spp total), max_depth {args.max_depth}, "
+                                   f"seed 95, counter RNG; rows sharded in bands of {args.band} over {world} GPU(s)"
+                                   + (", RCCL all_gather of the f32 framebuffer per step" if world > 1 else ""),
+                       "paths_per_step": int(s0.n_paths) * world, "rays_per_step_rank0": int(s0.n_rays),
+                       "rays_per_path": round(s0.n_rays / max(s0.n_paths, 1), 4),
+                       "spp_slices": int(s0.n_slices)},
+            "roofline": {"kernel": "k_trace_shade", "bound": "hbm", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                         "traffic": None,
+                         "bytes_per_launch": round(trace_bytes / max(launches, 1), 1),
+                         "avg_launch_us": round(trace_s / max(launches, 1) * 1e6, 3),
+                         "launches": launches,
+                         "note": "algorithmic bytes = 48 B/ray read + 48 B/surviving ray written + 12 B/path radiance "
+                                 "(SURVEY.md 8(d): 96 B/ray + 24 B/path over gen+trace+resolve); time = HIP events "
+                                 "around the trace launches of every slice on the launch stream"},
+            "whole_path": {"bytes_algorithmic_per_step": int(s0.bytes_algorithmic),
+                           "device_seconds_per_step": round(s0.seconds_device, 6),
+                           "hbm_frac": round(s0.bytes_algorithmic / max(s0.seconds_device, 1e-12) / 1e9 / HBM_PEAK_GBPS, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rt, scene, nx, ny, args.max_depth)
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 2)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    renderer.close()
+
+
+if __name__ == "__main__":
+    main()

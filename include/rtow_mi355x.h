@@ -159,6 +159,9 @@ typedef struct RtParams {
 } RtParams;
 
 #define RT_FLAG_NONE 0u
+/* Closest hit by the plain list walk (HitableList::hit order, hitable.rs:117-132) instead of the
+ * LDS-resident BVH.  Results are identical either way; the flag exists for cross-checking. */
+#define RT_FLAG_BRUTE_FORCE 1u
 
 typedef struct RtStats {
     uint64_t n_paths;          /* nx_rows_local * nx * spp                                   */
@@ -237,6 +240,7 @@ typedef struct RtBounceIO {
     float* out_o;              /* [3n] scattered ray */
     float* out_d;              /* [3n] */
     uint8_t* out_alive;        /* [n] 1 = scatter returned true */
+    uint32_t flags;            /* RT_FLAG_* (RT_FLAG_BRUTE_FORCE selects the list walk) */
 } RtBounceIO;
 int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io);
 

@@ -12,6 +12,7 @@ GPU_LIB_PATH = os.path.join(_PKG_DIR, "librtow_mi355x.so")
 HOST_LIB_PATH = os.path.join(_PKG_DIR, "librtow_host.so")
 
 RT_NO_TEX = 0xFFFFFFFF
+FLAG_BRUTE_FORCE = 1
 RTH_INVALID = 0xFFFFFFFF
 
 # enum RtMatType
@@ -74,7 +75,7 @@ class RtStats(C.Structure):
 class RtBounceIO(C.Structure):
     _fields_ = [("n", C.c_uint32), ("depth", C.c_uint32), ("in_o", _f), ("in_d", _f), ("in_key", _u32),
                 ("out_hit", C.POINTER(C.c_int32)), ("out_t", _f), ("out_radiance", _f), ("out_attenuation", _f),
-                ("out_o", _f), ("out_d", _f), ("out_alive", _u8)]
+                ("out_o", _f), ("out_d", _f), ("out_alive", _u8), ("flags", C.c_uint32)]
 
 
 GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",

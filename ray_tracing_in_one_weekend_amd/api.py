@@ -149,8 +149,9 @@ class Scene:
             pass
 
 
-def make_params(nx, ny, spp, max_depth=50, seed=95, shard_band=0, shard_count=1, shard_id=0, spp_slice=0):
+def make_params(nx, ny, spp, max_depth=50, seed=95, shard_band=0, shard_count=1, shard_id=0, spp_slice=0, flags=0):
     p = RtParams()
+    p.flags = flags
     p.nx, p.ny, p.spp, p.max_depth, p.seed = nx, ny, spp, max_depth, seed
     p.shard_band, p.shard_count, p.shard_id, p.spp_slice = shard_band, shard_count, shard_id, spp_slice
     return p
@@ -202,7 +203,7 @@ class Renderer:
             self._raise("rt_render_device", rc)
         return stats
 
-    def debug_bounce(self, origins, dirs, keys, depth=0):
+    def debug_bounce(self, origins, dirs, keys, depth=0, flags=0):
         """One closest-hit + shade step for caller-given rays (rt_debug_bounce)."""
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
@@ -213,7 +214,7 @@ class Renderer:
                "d": np.zeros((n, 3), np.float32), "alive": np.zeros(n, np.uint8)}
         io = RtBounceIO()
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
-        io.n, io.depth = n, depth
+        io.n, io.depth, io.flags = n, depth, flags
         io.in_o, io.in_d, io.in_key = fp(o), fp(d), k.ctypes.data_as(C.POINTER(C.c_uint32))
         io.out_hit = out["hit"].ctypes.data_as(C.POINTER(C.c_int32))
         io.out_t, io.out_radiance, io.out_attenuation = fp(out["t"]), fp(out["radiance"]), fp(out["attenuation"])

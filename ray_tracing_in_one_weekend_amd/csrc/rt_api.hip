@@ -3,6 +3,7 @@
 // of a slice is enqueued without any host synchronisation (queue sizes live in HBM).
 #include "../../include/rtow_mi355x.h"
 #include "rt_kernels.h"
+#include "rt_bvh.h"
 
 #include <hip/hip_runtime.h>
 
@@ -41,6 +42,9 @@ struct RtCtx {
     std::vector<hipEvent_t> events;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int n_cu = 256;
+    size_t lds_limit = 64 * 1024;
+    bool use_bvh = false;      // scene BVH fits LDS next to the traversal stacks
+    size_t bvh_lds = 0;
 };
 
 namespace {
@@ -145,6 +149,7 @@ int rt_ctx_create(int device_id, RtCtx** out_ctx) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->lds_limit = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 64 * 1024; // 160 KiB on gfx950
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail("hipEventCreate", e);
@@ -274,21 +279,37 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         for (size_t p = 0; p < np; ++p) texels[off + p] = make_float4(src[3 * p], src[3 * p + 1], src[3 * p + 2], 0.0f);
     }
 
+    HostBvh bvh;
+    build_sphere_bvh(geo, RT_BVH_STACK, bvh);
+
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
     DevScene ds{};
+    ds.n_bvh_nodes = (uint32_t)bvh.a.size();
+    ds.bvh_depth = bvh.depth;
     ds.n_spheres = s->n_spheres, ds.n_materials = s->n_materials, ds.n_textures = s->n_textures;
     ds.n_perlin = s->n_perlin, ds.n_images = s->n_images, ds.sky_type = s->sky_type, ds.sky_image = s->sky_image;
     int rc;
     if ((rc = upload(ctx, geo, &ds.sph_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
         (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
-        (rc = upload(ctx, texels, &ds.texels))) {
+        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, bvh.a, &ds.bvh_a)) || (rc = upload(ctx, bvh.b, &ds.bvh_b)) ||
+        (rc = upload(ctx, bvh.c, &ds.bvh_c)) || (rc = upload(ctx, bvh.d, &ds.bvh_d))) {
         free_scene(ctx);
         return rc;
     }
     ctx->ds = ds;
     ctx->has_scene = true;
+    // BVH traversal needs nodes + spheres + one stack column per lane in LDS (1024-thread workgroups)
+    ctx->bvh_lds = bvh_lds_bytes(ds.n_bvh_nodes, ds.n_spheres, RT_BVH_BLOCK);
+    ctx->use_bvh = ds.n_spheres > 0 && ds.n_bvh_nodes > 0 && ds.n_bvh_nodes < 32768 && ds.n_spheres <= 32768 &&
+                   bvh.depth <= RT_BVH_STACK && ctx->bvh_lds <= ctx->lds_limit;
+    if (ctx->use_bvh) {
+        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_shade<RT_BVH_BLOCK, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->bvh_lds));
+        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->bvh_lds));
+    }
     return RT_OK;
 }
 
@@ -333,7 +354,11 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t nchunks = (n_max + 255u) / 256u;
     const uint32_t cap = ((nchunks + nq - 1) / nq) * 256u;
     const int n_depths = prm->max_depth + 1;
-    const uint32_t blocks_per_shard = (uint32_t)std::max(1, (ctx->n_cu * 8) / (int)nq);
+    const bool use_bvh = ctx->use_bvh && !(prm->flags & RT_FLAG_BRUTE_FORCE);
+    // brute force: 256-thread workgroups, 8 per CU; BVH: 1024-thread workgroups sharing one LDS copy
+    // of the tree, one per CU
+    const uint32_t wg_per_cu = use_bvh ? 1u : 8u; // 1024 threads x ~115 VGPRs fill a CU's register file
+    const uint32_t blocks_per_shard = (uint32_t)std::max(1u, ((uint32_t)ctx->n_cu * wg_per_cu) / nq);
     const uint32_t grid = nq * blocks_per_shard;
 
     const size_t qbytes = (size_t)nq * cap * sizeof(float4);
@@ -358,7 +383,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     unsigned long long* totals = (unsigned long long*)ctx->totals.p; // [0]=tex fetches [1]=bad dirs [2..]=rays per depth
 
-    const size_t lds_bytes = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
+    const size_t lds_bytes = use_bvh ? ctx->bvh_lds
+                                     : (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
 
     RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
     RT_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * 3 * sizeof(float), st));
@@ -387,8 +413,14 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl], st));
         for (int depth = 0; depth < n_depths; ++depth) {
             TraceParams tp{nq, cap, depth, prm->max_depth};
-            hipLaunchKernelGGL(k_trace_shade, dim3(grid), dim3(256), lds_bytes, st, ctx->ds, Q[depth & 1], Q[(depth + 1) & 1],
-                               counts + (size_t)depth * nq, counts + (size_t)(depth + 1) * nq, rad, tp, totals);
+            if (use_bvh)
+                hipLaunchKernelGGL((k_trace_shade<RT_BVH_BLOCK, true>), dim3(grid), dim3(RT_BVH_BLOCK), lds_bytes, st, ctx->ds,
+                                   Q[depth & 1], Q[(depth + 1) & 1], counts + (size_t)depth * nq,
+                                   counts + (size_t)(depth + 1) * nq, rad, tp, totals);
+            else
+                hipLaunchKernelGGL((k_trace_shade<256, false>), dim3(grid), dim3(256), lds_bytes, st, ctx->ds, Q[depth & 1],
+                                   Q[(depth + 1) & 1], counts + (size_t)depth * nq, counts + (size_t)(depth + 1) * nq, rad, tp,
+                                   totals);
             ++n_trace_launches;
         }
         RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl + 1], st));
@@ -477,10 +509,19 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
     RT_HIP(ctx, hipMemcpyAsync(base + off_o, io->in_o, 3 * n * 4, hipMemcpyHostToDevice, st));
     RT_HIP(ctx, hipMemcpyAsync(base + off_d, io->in_d, 3 * n * 4, hipMemcpyHostToDevice, st));
     RT_HIP(ctx, hipMemcpyAsync(base + off_key, io->in_key, 2 * n * 4, hipMemcpyHostToDevice, st));
-    const size_t lds_bytes = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
-    hipLaunchKernelGGL(k_debug_bounce, dim3((unsigned)((n + 255) / 256)), dim3(256), lds_bytes, st, ctx->ds, (uint32_t)n,
-                       (int)io->depth, base + off_o, base + off_d, (const uint32_t*)(base + off_key), (int*)(base + off_hit),
-                       base + off_t, base + off_rad, base + off_att, base + off_so, base + off_sd, (uint8_t*)(base + off_alive));
+    const bool use_bvh = ctx->use_bvh && !(io->flags & RT_FLAG_BRUTE_FORCE);
+    if (use_bvh) {
+        hipLaunchKernelGGL((k_debug_bounce<RT_BVH_BLOCK, true>), dim3((unsigned)((n + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK)),
+                           dim3(RT_BVH_BLOCK), ctx->bvh_lds, st, ctx->ds, (uint32_t)n, (int)io->depth, base + off_o, base + off_d,
+                           (const uint32_t*)(base + off_key), (int*)(base + off_hit), base + off_t, base + off_rad, base + off_att,
+                           base + off_so, base + off_sd, (uint8_t*)(base + off_alive));
+    } else {
+        const size_t lds_bytes = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
+        hipLaunchKernelGGL((k_debug_bounce<256, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), lds_bytes, st, ctx->ds,
+                           (uint32_t)n, (int)io->depth, base + off_o, base + off_d, (const uint32_t*)(base + off_key),
+                           (int*)(base + off_hit), base + off_t, base + off_rad, base + off_att, base + off_so, base + off_sd,
+                           (uint8_t*)(base + off_alive));
+    }
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipMemcpyAsync(io->out_hit, base + off_hit, n * 4, hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipMemcpyAsync(io->out_t, base + off_t, n * 4, hipMemcpyDeviceToHost, st));

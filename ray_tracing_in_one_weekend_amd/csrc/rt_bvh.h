@@ -1,0 +1,180 @@
+// rt_bvh.h — host-side builder of the sphere BVH that the trace kernel stages into LDS.
+//
+// The reference accelerates closest-hit with a random-axis median-split BVH of trait objects
+// (hitable.rs:158-241).  The GPU path keeps the RESULT of HitableList::hit (hitable.rs:117-132:
+// the closest root, ties to the later sphere) but searches with its own structure: a binned-SAH
+// BVH2 whose nodes hold both child boxes (one LDS fetch per visit decides both children),
+// single-sphere leaves, boxes padded so that culling is conservative with respect to the exact
+// Sphere::hit arithmetic.  Culling never changes which sphere wins, so results are identical to
+// the brute-force list walk (tests/test_gpu_parity.py::test_bvh_equals_brute_force).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace rt {
+
+struct HostBvh {
+    std::vector<float4> a, b, c;
+    std::vector<int4> d;
+    uint32_t depth = 0;
+};
+
+namespace bvh_detail {
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) mn[k] = FLT_MAX, mx[k] = -FLT_MAX;
+    }
+    void grow(const Box& o) {
+        for (int k = 0; k < 3; ++k) mn[k] = std::min(mn[k], o.mn[k]), mx[k] = std::max(mx[k], o.mx[k]);
+    }
+    float half_area() const {
+        float e0 = mx[0] - mn[0], e1 = mx[1] - mn[1], e2 = mx[2] - mn[2];
+        return e0 * e1 + e1 * e2 + e2 * e0;
+    }
+};
+
+struct Builder {
+    const std::vector<float4>& geo;
+    std::vector<Box> boxes;     // padded sphere boxes
+    std::vector<uint32_t> order;
+    HostBvh& out;
+    bool median_only;
+
+    Builder(const std::vector<float4>& g, HostBvh& o, bool median) : geo(g), out(o), median_only(median) {
+        boxes.resize(g.size());
+        order.resize(g.size());
+        for (size_t i = 0; i < g.size(); ++i) {
+            order[i] = (uint32_t)i;
+            const float c[3] = {g[i].x, g[i].y, g[i].z};
+            const float r = std::fabs(g[i].w);
+            for (int k = 0; k < 3; ++k) {
+                // pad: 2^-18 of the coordinate magnitude, >= 10x the fp32 error of the exact test
+                float pad = (std::fabs(c[k]) + r) * 3.8146973e-06f + 1e-30f;
+                boxes[i].mn[k] = c[k] - r - pad;
+                boxes[i].mx[k] = c[k] + r + pad;
+                if (!(boxes[i].mn[k] <= boxes[i].mx[k])) { // NaN/inf sphere: never cull it
+                    boxes[i].mn[k] = -FLT_MAX, boxes[i].mx[k] = FLT_MAX;
+                }
+            }
+        }
+    }
+
+    Box range_box(size_t first, size_t count) const {
+        Box b;
+        b.reset();
+        for (size_t i = first; i < first + count; ++i) b.grow(boxes[order[i]]);
+        return b;
+    }
+
+    // returns child reference: >= 0 inner node index, < 0 ~sphere
+    int build(size_t first, size_t count, uint32_t depth) {
+        out.depth = std::max(out.depth, depth);
+        if (count == 1) return ~(int)order[first];
+        // centroid bounds
+        float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (size_t i = first; i < first + count; ++i) {
+            const float4& g = geo[order[i]];
+            const float c[3] = {g.x, g.y, g.z};
+            for (int k = 0; k < 3; ++k) cmn[k] = std::min(cmn[k], c[k]), cmx[k] = std::max(cmx[k], c[k]);
+        }
+        int axis = 0;
+        float ext = cmx[0] - cmn[0];
+        for (int k = 1; k < 3; ++k)
+            if (cmx[k] - cmn[k] > ext) ext = cmx[k] - cmn[k], axis = k;
+        auto cen = [&](uint32_t id) { return axis == 0 ? geo[id].x : (axis == 1 ? geo[id].y : geo[id].z); };
+        size_t mid = first + count / 2;
+        bool done = false;
+        if (!median_only && ext > 0.0f && count > 2) {
+            const int NB = 16;
+            Box bb[NB];
+            size_t bn[NB] = {0};
+            for (int k = 0; k < NB; ++k) bb[k].reset();
+            const float scale = (float)NB / ext;
+            auto bin_of = [&](uint32_t id) { return std::min(NB - 1, std::max(0, (int)((cen(id) - cmn[axis]) * scale))); };
+            for (size_t i = first; i < first + count; ++i) {
+                int k = bin_of(order[i]);
+                bb[k].grow(boxes[order[i]]);
+                ++bn[k];
+            }
+            float right_area[NB];
+            size_t right_n[NB];
+            Box acc;
+            acc.reset();
+            size_t n = 0;
+            for (int k = NB - 1; k >= 1; --k) {
+                if (bn[k]) acc.grow(bb[k]);
+                n += bn[k];
+                right_area[k] = n ? acc.half_area() : 0.0f;
+                right_n[k] = n;
+            }
+            acc.reset();
+            n = 0;
+            float best = FLT_MAX;
+            int best_k = -1;
+            for (int k = 0; k < NB - 1; ++k) {
+                if (bn[k]) acc.grow(bb[k]);
+                n += bn[k];
+                if (n == 0 || right_n[k + 1] == 0) continue;
+                float cost = acc.half_area() * (float)n + right_area[k + 1] * (float)right_n[k + 1];
+                if (cost < best) best = cost, best_k = k;
+            }
+            if (best_k >= 0) {
+                auto it = std::stable_partition(order.begin() + (long)first, order.begin() + (long)(first + count),
+                                                [&](uint32_t id) { return bin_of(id) <= best_k; });
+                mid = (size_t)(it - order.begin());
+                done = mid > first && mid < first + count;
+            }
+        }
+        if (!done) {
+            mid = first + count / 2;
+            std::stable_sort(order.begin() + (long)first, order.begin() + (long)(first + count),
+                             [&](uint32_t x, uint32_t y) { return cen(x) < cen(y); });
+        }
+        const int me = (int)out.a.size();
+        out.a.push_back(float4{}), out.b.push_back(float4{}), out.c.push_back(float4{}), out.d.push_back(int4{});
+        const Box lb = range_box(first, mid - first), rb = range_box(mid, first + count - mid);
+        const int l = build(first, mid - first, depth + 1);
+        const int r = build(mid, first + count - mid, depth + 1);
+        out.a[(size_t)me] = make_float4(lb.mn[0], lb.mn[1], lb.mn[2], lb.mx[0]);
+        out.b[(size_t)me] = make_float4(lb.mx[1], lb.mx[2], rb.mn[0], rb.mn[1]);
+        out.c[(size_t)me] = make_float4(rb.mn[2], rb.mx[0], rb.mx[1], rb.mx[2]);
+        out.d[(size_t)me] = make_int4(l, r, 0, 0);
+        return me;
+    }
+};
+
+} // namespace bvh_detail
+
+// Builds the BVH for `geo` = (cx, cy, cz, r).  The root is always inner node 0 (a single sphere
+// gets an empty right child).  `max_depth` bounds the traversal stack: if the SAH tree is deeper,
+// a median-split tree (depth <= ceil(log2 n) + 1) is built instead.
+inline void build_sphere_bvh(const std::vector<float4>& geo, uint32_t max_depth, HostBvh& out) {
+    out = HostBvh();
+    if (geo.empty()) return;
+    if (geo.size() == 1) {
+        bvh_detail::Builder b(geo, out, true);
+        const bvh_detail::Box& bx = b.boxes[0];
+        out.a.push_back(make_float4(bx.mn[0], bx.mn[1], bx.mn[2], bx.mx[0]));
+        out.b.push_back(make_float4(bx.mx[1], bx.mx[2], FLT_MAX, FLT_MAX));
+        out.c.push_back(make_float4(FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX));
+        out.d.push_back(make_int4(~0, INT_MIN, 0, 0));
+        out.depth = 1;
+        return;
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        out = HostBvh();
+        bvh_detail::Builder b(geo, out, attempt == 1);
+        b.build(0, geo.size(), 0);
+        if (out.depth <= max_depth) return;
+    }
+}
+
+} // namespace rt

@@ -190,6 +190,15 @@ struct DevScene {
     const uint8_t* perlin_perm; // [n_perlin*3*256]
     const ImgRec* imgs;
     const float4* texels;       // rgb_
+    // LDS-resident BVH2 over the spheres, built at upload (rt_bvh.h); children boxes live in
+    // the parent: A = (lmin.xyz, lmax.x) B = (lmax.yz, rmin.xy) C = (rmin.z, rmax.xyz),
+    // D = (left, right, 0, 0); child >= 0: inner node, child < 0: sphere ~child, INT_MIN: empty
+    uint32_t n_bvh_nodes;
+    uint32_t bvh_depth;
+    const float4* bvh_a;
+    const float4* bvh_b;
+    const float4* bvh_c;
+    const int4* bvh_d;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -104,27 +104,111 @@ struct TraceParams {
     int depth, max_depth;
 };
 
-__global__ __launch_bounds__(256) void k_trace_shade(DevScene sc, Queue qin, Queue qout,
-                                                     const uint32_t* __restrict__ in_counts,
-                                                     uint32_t* __restrict__ out_counts, float* __restrict__ rad,
-                                                     TraceParams tp, unsigned long long* __restrict__ stats) {
+#define RT_BVH_STACK 32 // traversal stack entries per lane (u16 each, in LDS)
+#define RT_BVH_BLOCK 1024 // threads per workgroup of the BVH trace kernel (one LDS copy of the tree)
+
+// LDS carve of the BVH trace kernel: node arrays A,B,C,D (16 B per node each), sphere list
+// (16 B each), then the per-lane traversal stack laid out [level][thread] (conflict-free).
+__host__ __device__ inline size_t bvh_lds_bytes(uint32_t n_nodes, uint32_t n_spheres, uint32_t block) {
+    return (size_t)n_nodes * 64u + (size_t)n_spheres * 16u + (size_t)block * RT_BVH_STACK * 2u;
+}
+
+// Closest hit by BVH traversal.  Same result as closest_hit_tile over the whole list: the
+// winner is the smallest accepted root, ties go to the larger sphere index (= the later list
+// entry, hitable.rs:122-126 with the `t_max < root` acceptance of hitable.rs:86), whatever the
+// visiting order.  Boxes are padded at build time and the exit distance is widened by a few ulp,
+// so a box is never culled when the exact sphere test could accept.
+template <int BLOCK>
+__device__ __forceinline__ void closest_hit_bvh(const float4* nA, const float4* nB, const float4* nC, const int4* nD,
+                                                const float4* s_geo, unsigned short* stack, V3 o, V3 d, float a,
+                                                float& tbest, int& hit) {
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    int sp = 0;
+    int cur = 0; // root = inner node 0
+    for (;;) {
+        if (cur >= 0) {
+            const float4 A = nA[cur], B = nB[cur], C = nC[cur];
+            const int4 D = nD[cur];
+            // left child box: min (A.x, A.y, A.z) max (A.w, B.x, B.y)
+            float x0 = (A.x - o.x) * ix, x1 = (A.w - o.x) * ix;
+            float y0 = (A.y - o.y) * iy, y1 = (B.x - o.y) * iy;
+            float z0 = (A.z - o.z) * iz, z1 = (B.y - o.z) * iz;
+            float tnl = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+            float tfl = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            // right child box: min (B.z, B.w, C.x) max (C.y, C.z, C.w)
+            x0 = (B.z - o.x) * ix, x1 = (C.y - o.x) * ix;
+            y0 = (B.w - o.y) * iy, y1 = (C.z - o.y) * iy;
+            z0 = (C.x - o.z) * iz, z1 = (C.w - o.z) * iz;
+            float tnr = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+            float tfr = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+            const bool hl = tnl * 0.999998f <= fminf(tfl * 1.000002f, tbest) && D.x != (int)0x80000000;
+            const bool hr = tnr * 0.999998f <= fminf(tfr * 1.000002f, tbest) && D.y != (int)0x80000000;
+            if (hl && hr) {
+                const bool left_first = tnl <= tnr;
+                stack[sp * BLOCK] = (unsigned short)(left_first ? D.y : D.x);
+                ++sp;
+                cur = left_first ? D.x : D.y;
+            } else if (hl) {
+                cur = D.x;
+            } else if (hr) {
+                cur = D.y;
+            } else {
+                if (sp == 0) break;
+                --sp;
+                cur = (int)(short)stack[sp * BLOCK];
+            }
+        } else {
+            const int s = ~cur;
+            float th;
+            // candidate root of this sphere (independent of tbest), then order-independent accept
+            if (sphere_root(s_geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th) && (th < tbest || (th == tbest && s > hit))) {
+                tbest = th;
+                hit = s;
+            }
+            if (sp == 0) break;
+            --sp;
+            cur = (int)(short)stack[sp * BLOCK];
+        }
+    }
+}
+
+// One chunk-loop body shared by both closest-hit strategies: shade, retire or compact.
+template <int BLOCK, bool USE_BVH>
+__global__ __launch_bounds__(BLOCK) void k_trace_shade(DevScene sc, Queue qin, Queue qout,
+                                                       const uint32_t* __restrict__ in_counts,
+                                                       uint32_t* __restrict__ out_counts, float* __restrict__ rad,
+                                                       TraceParams tp, unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* s_geo = reinterpret_cast<float4*>(smem);
     const uint32_t q = blockIdx.x % tp.nq;
     const uint32_t bq = blockIdx.x / tp.nq;
     const uint32_t nbq = gridDim.x / tp.nq;
     const uint32_t count = in_counts[q];
-    if (bq * 256u >= count) return; // block-uniform: nothing queued for this workgroup
+    if (bq * BLOCK >= count) return; // block-uniform: nothing queued for this workgroup
     const uint32_t n_sph = sc.n_spheres;
-    const bool single_tile = n_sph <= RT_SPHERE_TILE;
+    // LDS carve
+    float4* nA = reinterpret_cast<float4*>(smem);
+    float4* nB = nA + (USE_BVH ? sc.n_bvh_nodes : 0u);
+    float4* nC = nB + (USE_BVH ? sc.n_bvh_nodes : 0u);
+    int4* nD = reinterpret_cast<int4*>(nC + (USE_BVH ? sc.n_bvh_nodes : 0u));
+    float4* s_geo = reinterpret_cast<float4*>(nD + (USE_BVH ? sc.n_bvh_nodes : 0u));
+    unsigned short* stack = reinterpret_cast<unsigned short*>(s_geo + (USE_BVH ? n_sph : 0u)) + threadIdx.x;
+    const bool single_tile = USE_BVH || n_sph <= RT_SPHERE_TILE;
     if (single_tile) {
-        for (uint32_t i = threadIdx.x; i < n_sph; i += 256u) s_geo[i] = sc.sph_geo[i];
+        for (uint32_t i = threadIdx.x; i < n_sph; i += BLOCK) s_geo[i] = sc.sph_geo[i];
+        if (USE_BVH) {
+            for (uint32_t i = threadIdx.x; i < sc.n_bvh_nodes; i += BLOCK) {
+                nA[i] = sc.bvh_a[i];
+                nB[i] = sc.bvh_b[i];
+                nC[i] = sc.bvh_c[i];
+                nD[i] = sc.bvh_d[i];
+            }
+        }
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t n_fetch = 0, n_bad = 0;
     const size_t qbase = (size_t)q * tp.cap;
-    for (uint32_t base = bq * 256u; base < count; base += nbq * 256u) {
+    for (uint32_t base = bq * BLOCK; base < count; base += nbq * BLOCK) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < count;
         float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 1.f, 0.f), rc = ra;
@@ -139,13 +223,15 @@ __global__ __launch_bounds__(256) void k_trace_shade(DevScene sc, Queue qin, Que
         float tbest = RT_FLT_MAX;
         int hit = -1;
         const float a = length_squared(d); // hitable.rs:77
-        if (single_tile) {
+        if (USE_BVH) {
+            if (active && n_sph) closest_hit_bvh<BLOCK>(nA, nB, nC, nD, s_geo, stack, o, d, a, tbest, hit);
+        } else if (single_tile) {
             closest_hit_tile(s_geo, n_sph, 0u, o, d, a, tbest, hit);
         } else {
             for (uint32_t t0 = 0; t0 < n_sph; t0 += RT_SPHERE_TILE) {
                 const uint32_t n = min(RT_SPHERE_TILE, n_sph - t0);
                 __syncthreads();
-                for (uint32_t k = threadIdx.x; k < n; k += 256u) s_geo[k] = sc.sph_geo[t0 + k];
+                for (uint32_t k = threadIdx.x; k < n; k += BLOCK) s_geo[k] = sc.sph_geo[t0 + k];
                 __syncthreads();
                 closest_hit_tile(s_geo, n, t0, o, d, a, tbest, hit);
             }
@@ -250,15 +336,15 @@ __global__ void k_accum_counts(const uint32_t* __restrict__ counts, uint32_t nq,
 }
 
 // Test hook: one bounce for caller-given rays, no compaction (rt_debug_bounce).
-__global__ __launch_bounds__(256) void k_debug_bounce(DevScene sc, uint32_t n, int depth, const float* __restrict__ in_o,
-                                                      const float* __restrict__ in_d, const uint32_t* __restrict__ in_key,
-                                                      int* __restrict__ out_hit, float* __restrict__ out_t,
-                                                      float* __restrict__ out_rad, float* __restrict__ out_att,
-                                                      float* __restrict__ out_o, float* __restrict__ out_d,
-                                                      uint8_t* __restrict__ out_alive) {
+template <int BLOCK, bool USE_BVH>
+__global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n, int depth, const float* __restrict__ in_o,
+                                                        const float* __restrict__ in_d, const uint32_t* __restrict__ in_key,
+                                                        int* __restrict__ out_hit, float* __restrict__ out_t,
+                                                        float* __restrict__ out_rad, float* __restrict__ out_att,
+                                                        float* __restrict__ out_o, float* __restrict__ out_d,
+                                                        uint8_t* __restrict__ out_alive) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* s_geo = reinterpret_cast<float4*>(smem);
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool active = i < n;
     V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
     if (active) {
@@ -268,12 +354,31 @@ __global__ __launch_bounds__(256) void k_debug_bounce(DevScene sc, uint32_t n, i
     float tbest = RT_FLT_MAX;
     int hit = -1;
     const float a = length_squared(d);
-    for (uint32_t t0 = 0; t0 < sc.n_spheres; t0 += RT_SPHERE_TILE) {
-        const uint32_t nn = min(RT_SPHERE_TILE, sc.n_spheres - t0);
+    if (USE_BVH) {
+        float4* nA = reinterpret_cast<float4*>(smem);
+        float4* nB = nA + sc.n_bvh_nodes;
+        float4* nC = nB + sc.n_bvh_nodes;
+        int4* nD = reinterpret_cast<int4*>(nC + sc.n_bvh_nodes);
+        float4* s_geo = reinterpret_cast<float4*>(nD + sc.n_bvh_nodes);
+        unsigned short* stack = reinterpret_cast<unsigned short*>(s_geo + sc.n_spheres) + threadIdx.x;
+        for (uint32_t k = threadIdx.x; k < sc.n_spheres; k += BLOCK) s_geo[k] = sc.sph_geo[k];
+        for (uint32_t k = threadIdx.x; k < sc.n_bvh_nodes; k += BLOCK) {
+            nA[k] = sc.bvh_a[k];
+            nB[k] = sc.bvh_b[k];
+            nC[k] = sc.bvh_c[k];
+            nD[k] = sc.bvh_d[k];
+        }
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < nn; k += 256u) s_geo[k] = sc.sph_geo[t0 + k];
-        __syncthreads();
-        closest_hit_tile(s_geo, nn, t0, o, d, a, tbest, hit);
+        if (active && sc.n_spheres) closest_hit_bvh<BLOCK>(nA, nB, nC, nD, s_geo, stack, o, d, a, tbest, hit);
+    } else {
+        float4* s_geo = reinterpret_cast<float4*>(smem);
+        for (uint32_t t0 = 0; t0 < sc.n_spheres; t0 += RT_SPHERE_TILE) {
+            const uint32_t nn = min(RT_SPHERE_TILE, sc.n_spheres - t0);
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < nn; k += BLOCK) s_geo[k] = sc.sph_geo[t0 + k];
+            __syncthreads();
+            closest_hit_tile(s_geo, nn, t0, o, d, a, tbest, hit);
+        }
     }
     if (!active) return;
     uint32_t n_fetch = 0;

@@ -26,7 +26,10 @@ def _oracle(orc, scene, params, **kw):
 def _check_bounce(rt, orc, renderer, scene, n=20000, depth=0, seed=1):
     o, d, keys = rays_on_scene(n, seed)
     renderer.upload(scene)
-    g = renderer.debug_bounce(o, d, keys, depth=depth)
+    g = renderer.debug_bounce(o, d, keys, depth=depth)  # LDS BVH traversal
+    b = renderer.debug_bounce(o, d, keys, depth=depth, flags=rt._ffi.FLAG_BRUTE_FORCE)  # list walk
+    for k in g:
+        assert np.array_equal(g[k].view(np.uint8), b[k].view(np.uint8)), k  # BVH culling never changes the result
     c = orc.debug_bounce(scene.flat_ptr, o, d, keys, depth=depth, accel=orc.ACCEL_LIST)
     assert np.array_equal(g["hit"], c["hit"])
     assert np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
@@ -84,6 +87,67 @@ def test_bounce_every_texture_and_sky(rt, orc, renderer, tex):
     _check_bounce(rt, orc, renderer, scene, n=20000, seed=5)
     scene = _single_material_scene(rt, rt._ffi.MAT_EMISSION, tex=tex, sky=rt._ffi.SKY_BLACK)
     _check_bounce(rt, orc, renderer, scene, n=20000, seed=6)
+
+
+def test_bvh_equals_brute_force_on_adversarial_rays(rt, orc, renderer):
+    """Axis-aligned directions (zero components -> infinite slab reciprocals), origins inside
+    spheres, on sphere surfaces, far away, and grazing rays: BVH == list walk == oracle, bit for bit."""
+    scene = rt.Scene.build("sphere_scene", 16 / 9)
+    renderer.upload(scene)
+    a = scene.arrays()
+    rng = np.random.default_rng(3)
+    c = np.stack([a["sph_cx"], a["sph_cy"], a["sph_cz"]], 1).astype(np.float64)
+    r = a["sph_r"].astype(np.float64)
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float32)
+    o_list, d_list = [], []
+    for k in range(4000):
+        s = rng.integers(0, len(r))
+        ax = axes[rng.integers(0, 6)]
+        kind = k % 5
+        if kind == 0:    # axis-aligned ray through a sphere centre from outside
+            o_list.append(c[s] - ax * (r[s] * 3 + 1)); d_list.append(ax)
+        elif kind == 1:  # origin at the centre of a sphere
+            o_list.append(c[s]); d_list.append(ax)
+        elif kind == 2:  # grazing: offset by exactly r perpendicular to the direction
+            perp = axes[(np.argmax(np.abs(ax)) * 2 + 2) % 6]
+            o_list.append(c[s] + perp * r[s] - ax * 5); d_list.append(ax)
+        elif kind == 3:  # very far origin
+            o_list.append(c[s] - ax * 1e6); d_list.append(ax)
+        else:            # random direction from a point on the sphere surface
+            v = rng.normal(size=3); v /= np.linalg.norm(v)
+            o_list.append(c[s] + v * r[s]); w = rng.normal(size=3).astype(np.float32)
+            w = w * (np.float32(1) / np.sqrt(np.float32(w[0] * w[0] + w[1] * w[1]) + np.float32(w[2] * w[2])))
+            d_list.append(w)
+    o = np.asarray(o_list, np.float32)
+    d = np.asarray(d_list, np.float32)
+    keys = rng.integers(0, 2**32, size=(len(o), 2), dtype=np.uint64).astype(np.uint32)
+    g = renderer.debug_bounce(o, d, keys)
+    b = renderer.debug_bounce(o, d, keys, flags=rt._ffi.FLAG_BRUTE_FORCE)
+    ref = orc.debug_bounce(scene.flat_ptr, o, d, keys, accel=orc.ACCEL_LIST)
+    # the GPU list walk is the oracle's HitableList::hit, bit for bit, on every ray
+    assert np.array_equal(b["hit"], ref["hit"]) and np.array_equal(b["t"].view(np.uint32), ref["t"].view(np.uint32))
+    kind = np.arange(len(o)) % 5
+    same = (g["hit"] == b["hit"]) & (g["t"].view(np.uint32) == b["t"].view(np.uint32))
+    # kinds 0,1,2,4: the BVH search returns exactly the list-walk result
+    assert same[kind != 3].all(), np.flatnonzero(~same & (kind != 3))[:10]
+    # kind 3 (origin 1e6 away): hitable.rs:79-80 cancels catastrophically (|oc|^2 ~ 1e12, ulp 65536), so the
+    # list walk reports "hits" on spheres the ray misses by up to hundreds of units; any box test culls them
+    # (the reference's own AABB test does too).  Where the two differ, the list-walk hit must be such a
+    # false positive in exact (float64) geometry.
+    for i in np.flatnonzero(~same):
+        sph = b["hit"][i]
+        assert sph >= 0
+        oc = o[i].astype(np.float64) - c[sph]
+        dd = d[i].astype(np.float64)
+        dist2 = oc @ oc - (oc @ dd) ** 2 / (dd @ dd)
+        assert dist2 > (r[sph] * (1 + 1e-6)) ** 2, (i, sph, dist2, r[sph])
+    assert (g["hit"] >= 0).mean() > 0.6
+    # whole renders agree bit for bit as well
+    p = rt.make_params(160, 90, 4, max_depth=50)
+    i1, _, s1 = renderer.render(scene.camera, p)
+    p.flags = rt._ffi.FLAG_BRUTE_FORCE
+    i2, _, s2 = renderer.render(scene.camera, p)
+    assert np.array_equal(i1.view(np.uint32), i2.view(np.uint32)) and s1.n_rays == s2.n_rays
 
 
 def test_render_config1_random_spheres(rt, orc, renderer):
