@@ -29,12 +29,25 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
+def usable_cores():
+    """Host cores this process may actually use: the cgroup CPU quota (cpu.max) caps the GPU box's
+    share well below os.cpu_count(), and oversubscribing the quota only adds throttling."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(rt, scene, nx, ny, max_depth, budget_s=15.0):
     """Times the oracle (kind "port": C++ restatement of the reference, stream RNG order, BVH,
     one worker per host core like threadpool's default) on a bounded sample of the workload:
     the same frame at reduced spp (Mray/s does not depend on spp)."""
     from oracle import binding as orc
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     opts = orc.options(rng_mode=orc.RNG_STREAM, estimator=orc.EST_RECURSIVE, accel=orc.ACCEL_BVH,
                        n_threads=cores, bvh_seed=1995, bvh_skip_perlin=1)
     probe = rt.make_params(nx, ny, 1, max_depth=max_depth, seed=95)

@@ -342,9 +342,10 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         return RT_OK;
     }
     const uint32_t npix = (uint32_t)npix64;
-    // slice size: bound the ray queue to ~32 Mi rays (3 GiB of queues), at least one sample
+    // slice size: bound the ray queue to ~256 Mi rays (24 GiB of queues out of 288 GB HBM): few, large
+    // slices amortise the short-queue tail of the bounce loop (depths > ~12 hold a few thousand rays)
     uint32_t S = prm->spp_slice;
-    if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (32ull << 20) / npix64);
+    if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (256ull << 20) / npix64);
     S = std::min(S, spp);
     if ((uint64_t)S * npix64 > 0xFFFFFF00ull) S = (uint32_t)(0xFFFFFF00ull / npix64);
     if (S == 0) return fail(ctx, RT_ERR_UNSUPPORTED, "render: shard has more than 2^32 pixels");

@@ -85,6 +85,8 @@ int rth_scene_build(const char* name, float aspect_ratio, RthScene** out) {
         else if (n == "earth_env_scene") fn = earth_env_scene;
         else if (n == "pbr_sweep_scene") fn = pbr_sweep_scene;
         else throw std::runtime_error("rth_scene_build: unknown scene '" + n + "'");
+        // the reference builds one scene per process, so the thread RNG starts from lib.rs:8's seed
+        RNG_reseed(1995);
         auto wc = fn(aspect_ratio);
         std::unique_ptr<RthScene> s(new RthScene());
         s->world = wc.first;
@@ -100,6 +102,7 @@ int rth_scene_new(RthScene** out) {
     return guarded([&] {
         if (!out) throw std::runtime_error("rth_scene_new: out is NULL");
         *out = new RthScene();
+        RNG_reseed(1995); // fresh-process RNG state (lib.rs:8); rth_rng_reseed() overrides
         SKY_COLOR_set(SkyFn::sky_color);
         return RT_OK;
     });
