@@ -162,6 +162,9 @@ typedef struct RtParams {
 /* Closest hit by the plain list walk (HitableList::hit order, hitable.rs:117-132) instead of the
  * LDS-resident BVH.  Results are identical either way; the flag exists for cross-checking. */
 #define RT_FLAG_BRUTE_FORCE 1u
+/* Record HIP events around the kernels of every depth of the FIRST slice; read them back with
+ * rt_get_depth_timings().  Diagnostic only (adds two event records per depth). */
+#define RT_FLAG_TIME_DEPTHS 4u
 
 typedef struct RtStats {
     uint64_t n_paths;          /* nx_rows_local * nx * spp                                   */
@@ -220,6 +223,12 @@ int rt_render(RtCtx* ctx, const RtCamera* cam, const RtParams* params, float* ou
  */
 int rt_render_device(RtCtx* ctx, const RtCamera* cam, const RtParams* params,
                      void* d_out_rgb_f32, void* stream, RtStats* stats);
+
+/* Per-depth device times of the first slice of the last render that had RT_FLAG_TIME_DEPTHS set:
+ * isect_ms[d] = closest-hit kernel, shade_ms[d] = shading kernel, rays[d] = rays traced at depth d
+ * in that slice.
+ * Returns the number of depths written (<= max_n), or a negative RT_ERR_*. */
+int rt_get_depth_timings(RtCtx* ctx, uint32_t max_n, float* isect_ms, float* shade_ms, uint64_t* rays);
 
 /* -- single-bounce evaluation (test hook) --------------------------------------------------
  * Runs ONE closest-hit + shade step (main.rs:44-58 for one depth) over `n` caller-given

@@ -8,11 +8,13 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-GPU_LIB_PATH = os.path.join(_PKG_DIR, "librtow_mi355x.so")
+# RTOW_GPU_LIB selects an alternative build of the SAME sources (A/B experiments, scripts/ only)
+GPU_LIB_PATH = os.environ.get("RTOW_GPU_LIB") or os.path.join(_PKG_DIR, "librtow_mi355x.so")
 HOST_LIB_PATH = os.path.join(_PKG_DIR, "librtow_host.so")
 
 RT_NO_TEX = 0xFFFFFFFF
 FLAG_BRUTE_FORCE = 1
+FLAG_TIME_DEPTHS = 4
 RTH_INVALID = 0xFFFFFFFF
 
 # enum RtMatType
@@ -79,7 +81,8 @@ class RtBounceIO(C.Structure):
 
 
 GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
-               "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce"]
+               "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce",
+               "rt_get_depth_timings"]
 HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
                 "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
                 "rth_sphere", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
@@ -121,6 +124,8 @@ def load_gpu_library():
     lib.rt_render.restype = C.c_int
     lib.rt_render_device.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), vp, vp, C.POINTER(RtStats)]
     lib.rt_render_device.restype = C.c_int
+    lib.rt_get_depth_timings.argtypes = [vp, C.c_uint32, _f, _f, _u64]
+    lib.rt_get_depth_timings.restype = C.c_int
     lib.rt_debug_bounce.argtypes = [vp, C.POINTER(RtBounceIO)]
     lib.rt_debug_bounce.restype = C.c_int
     _gpu_lib = lib

@@ -203,6 +203,17 @@ class Renderer:
             self._raise("rt_render_device", rc)
         return stats
 
+    def depth_timings(self, max_n=128):
+        """(isect_ms, shade_ms, rays) per depth of the first slice of the last render with FLAG_TIME_DEPTHS."""
+        a = np.zeros(max_n, np.float32)
+        b = np.zeros(max_n, np.float32)
+        r = np.zeros(max_n, np.uint64)
+        n = self._lib.rt_get_depth_timings(self._ctx, max_n, a.ctypes.data_as(C.POINTER(C.c_float)),
+                                           b.ctypes.data_as(C.POINTER(C.c_float)), r.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if n < 0:
+            self._raise("rt_get_depth_timings", n)
+        return a[:n], b[:n], r[:n]
+
     def debug_bounce(self, origins, dirs, keys, depth=0, flags=0):
         """One closest-hit + shade step for caller-given rays (rt_debug_bounce)."""
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

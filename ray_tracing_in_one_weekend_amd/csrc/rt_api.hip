@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,13 +39,16 @@ struct RtCtx {
     std::vector<void*> scene_allocs;
     // work buffers (grown on demand, reused across calls)
     DevBuf qbuf[6];   // two queues x (a, b, c)
-    DevBuf rad, acc, counts, totals, out_f32, out_u8, dbg;
+    DevBuf rad, acc, counts, totals, out_f32, out_u8, dbg, qhit;
     std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> depth_events;  // RT_FLAG_TIME_DEPTHS: 2 per depth + 1
+    int timed_depths = 0;
+    std::vector<unsigned long long> timed_rays;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     int n_cu = 256;
     size_t lds_limit = 64 * 1024;
     bool use_bvh = false;      // scene BVH fits LDS next to the traversal stacks
-    size_t bvh_lds = 0;
+    size_t isect_lds = 0;      // k_intersect: nodes + spheres + bvh_depth levels of stack + counters
 };
 
 namespace {
@@ -164,8 +168,9 @@ void rt_ctx_destroy(RtCtx* ctx) {
     free_scene(ctx);
     for (auto& b : ctx->qbuf) free_buf(b);
     free_buf(ctx->rad), free_buf(ctx->acc), free_buf(ctx->counts), free_buf(ctx->totals);
-    free_buf(ctx->out_f32), free_buf(ctx->out_u8), free_buf(ctx->dbg);
+    free_buf(ctx->out_f32), free_buf(ctx->out_u8), free_buf(ctx->dbg), free_buf(ctx->qhit);
     for (auto ev : ctx->events) (void)hipEventDestroy(ev);
+    for (auto ev : ctx->depth_events) (void)hipEventDestroy(ev);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -280,7 +285,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     }
 
     HostBvh bvh;
-    build_sphere_bvh(geo, RT_BVH_STACK, bvh);
+    build_sphere_bvh(geo, RT_BVH_MAX_DEPTH, bvh);
 
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
@@ -300,15 +305,15 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     }
     ctx->ds = ds;
     ctx->has_scene = true;
-    // BVH traversal needs nodes + spheres + one stack column per lane in LDS (1024-thread workgroups)
-    ctx->bvh_lds = bvh_lds_bytes(ds.n_bvh_nodes, ds.n_spheres, RT_BVH_BLOCK);
+    // k_intersect keeps nodes + spheres + one u16 stack column per lane (bvh.depth levels) in LDS
+    ctx->isect_lds = bvh_lds_bytes(ds.n_bvh_nodes, ds.n_spheres, RT_BVH_BLOCK, bvh.depth);
     ctx->use_bvh = ds.n_spheres > 0 && ds.n_bvh_nodes > 0 && ds.n_bvh_nodes < 32768 && ds.n_spheres <= 32768 &&
-                   bvh.depth <= RT_BVH_STACK && ctx->bvh_lds <= ctx->lds_limit;
+                   bvh.depth <= RT_BVH_MAX_DEPTH && ctx->isect_lds <= ctx->lds_limit;
     if (ctx->use_bvh) {
-        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace_shade<RT_BVH_BLOCK, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->bvh_lds));
+        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
         RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->bvh_lds));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
     }
     return RT_OK;
 }
@@ -342,7 +347,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         return RT_OK;
     }
     const uint32_t npix = (uint32_t)npix64;
-    // slice size: bound the ray queue to ~256 Mi rays (24 GiB of queues out of 288 GB HBM): few, large
+    // slice size: bound the ray queue to ~256 Mi rays (28 GiB of queues out of 288 GB HBM): few, large
     // slices amortise the short-queue tail of the bounce loop (depths > ~12 hold a few thousand rays)
     uint32_t S = prm->spp_slice;
     if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (256ull << 20) / npix64);
@@ -351,23 +356,29 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     if (S == 0) return fail(ctx, RT_ERR_UNSUPPORTED, "render: shard has more than 2^32 pixels");
     const uint32_t n_slices = (spp + S - 1) / S;
     const uint32_t n_max = npix * S;
-    const uint32_t nq = 32;
+    const int n_depths = prm->max_depth + 1;
+
+    // Queue shards: one per k_shade workgroup (8 workgroups of 256 threads per CU), each owned by one
+    // workgroup per kernel so that queue positions come from LDS counters (rt_kernels.h).
+    uint32_t nq = (uint32_t)ctx->n_cu * 8u;
+    if (const char* e = getenv("RTOW_NQ")) nq = (uint32_t)std::max(1, atoi(e)); // experiment knob (scripts/)
+    const bool use_bvh = ctx->use_bvh && !(prm->flags & RT_FLAG_BRUTE_FORCE);
+    // k_intersect: as many 1024-thread workgroups per CU as LDS admits (two at <= 64 VGPRs); every
+    // workgroup owns nq / isect_grid shards
+    const uint32_t isect_wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_limit / std::max<size_t>(ctx->isect_lds, 1)));
+    uint32_t isect_grid = std::min(nq, (uint32_t)ctx->n_cu * isect_wg_per_cu);
+    while ((nq + isect_grid - 1) / isect_grid > RT_ISECT_MAX_SHARDS) isect_grid *= 2;
+    isect_grid = std::min(isect_grid, nq);
     const uint32_t nchunks = (n_max + 255u) / 256u;
     const uint32_t cap = ((nchunks + nq - 1) / nq) * 256u;
-    const int n_depths = prm->max_depth + 1;
-    const bool use_bvh = ctx->use_bvh && !(prm->flags & RT_FLAG_BRUTE_FORCE);
-    // brute force: 256-thread workgroups, 8 per CU; BVH: 1024-thread workgroups sharing one LDS copy
-    // of the tree, one per CU
-    const uint32_t wg_per_cu = use_bvh ? 1u : 8u; // 1024 threads x ~115 VGPRs fill a CU's register file
-    const uint32_t blocks_per_shard = (uint32_t)std::max(1u, ((uint32_t)ctx->n_cu * wg_per_cu) / nq);
-    const uint32_t grid = nq * blocks_per_shard;
 
     const size_t qbytes = (size_t)nq * cap * sizeof(float4);
     for (auto& b : ctx->qbuf)
         if ((rc = ensure(ctx, b, qbytes))) return rc;
+    if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
     if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * 3 * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->acc, (size_t)npix * 3 * sizeof(float)))) return rc;
-    const size_t counts_bytes = (size_t)(n_depths + 1) * nq * sizeof(uint32_t);
+    const size_t counts_bytes = (size_t)(n_depths + 1) * nq * sizeof(uint32_t); // queue sizes [depth][shard]
     if ((rc = ensure(ctx, ctx->counts, counts_bytes))) return rc;
     const size_t totals_bytes = (size_t)(n_depths + 2) * sizeof(unsigned long long);
     if ((rc = ensure(ctx, ctx->totals, totals_bytes))) return rc;
@@ -379,13 +390,15 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     Queue Q[2];
     Q[0] = Queue{(float4*)ctx->qbuf[0].p, (float4*)ctx->qbuf[1].p, (float4*)ctx->qbuf[2].p};
     Q[1] = Queue{(float4*)ctx->qbuf[3].p, (float4*)ctx->qbuf[4].p, (float4*)ctx->qbuf[5].p};
+    float2* qhit = (float2*)ctx->qhit.p;
     float* rad = (float*)ctx->rad.p;
     float* acc = (float*)ctx->acc.p;
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     unsigned long long* totals = (unsigned long long*)ctx->totals.p; // [0]=tex fetches [1]=bad dirs [2..]=rays per depth
 
-    const size_t lds_bytes = use_bvh ? ctx->bvh_lds
-                                     : (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
+    const size_t list_lds = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
+    const bool perlin_lds = ctx->ds.n_perlin > 0 && ctx->ds.n_perlin <= RT_PERLIN_LDS_MAX_SETS;
+    const size_t shade_lds = 16u + (perlin_lds ? (size_t)ctx->ds.n_perlin * (256u * sizeof(float4) + 768u) : 0u);
 
     RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
     RT_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * 3 * sizeof(float), st));
@@ -404,6 +417,16 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     gp.seed_lo = (uint32_t)prm->seed, gp.seed_hi = (uint32_t)(prm->seed >> 32);
 
     uint32_t n_trace_launches = 0;
+    const bool time_depths = (prm->flags & RT_FLAG_TIME_DEPTHS) != 0;
+    ctx->timed_depths = 0;
+    if (time_depths) {
+        while (ctx->depth_events.size() < 2 * (size_t)n_depths + 1) {
+            hipEvent_t ev;
+            RT_HIP(ctx, hipEventCreate(&ev));
+            ctx->depth_events.push_back(ev);
+        }
+    }
+    const IntersectParams ip{nq, cap};
     for (uint32_t sl = 0; sl < n_slices; ++sl) {
         const uint32_t s0 = sl * S;
         const uint32_t sc = std::min(S, spp - s0);
@@ -413,20 +436,38 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         hipLaunchKernelGGL(k_gen_primary, dim3((gp.n_rays + 255u) / 256u), dim3(256), 0, st, gp, Q[0], counts);
         RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl], st));
         for (int depth = 0; depth < n_depths; ++depth) {
-            TraceParams tp{nq, cap, depth, prm->max_depth};
+            const Queue& qi = Q[depth & 1];
+            const Queue& qo = Q[(depth + 1) & 1];
+            const uint32_t* cin = counts + (size_t)depth * nq;
+            uint32_t* cout = counts + (size_t)(depth + 1) * nq;
+            const bool td = time_depths && sl == 0;
+            if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth], st));
             if (use_bvh)
-                hipLaunchKernelGGL((k_trace_shade<RT_BVH_BLOCK, true>), dim3(grid), dim3(RT_BVH_BLOCK), lds_bytes, st, ctx->ds,
-                                   Q[depth & 1], Q[(depth + 1) & 1], counts + (size_t)depth * nq,
-                                   counts + (size_t)(depth + 1) * nq, rad, tp, totals);
+                hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds,
+                                   qi.a, qi.b, qhit, cin, ip);
             else
-                hipLaunchKernelGGL((k_trace_shade<256, false>), dim3(grid), dim3(256), lds_bytes, st, ctx->ds, Q[depth & 1],
-                                   Q[(depth + 1) & 1], counts + (size_t)depth * nq, counts + (size_t)(depth + 1) * nq, rad, tp,
-                                   totals);
-            ++n_trace_launches;
+                hipLaunchKernelGGL(k_intersect_list, dim3(nq), dim3(256), list_lds, st, ctx->ds, qi.a, qi.b, qhit, cin, ip);
+            if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth + 1], st));
+            const ShadeParams sp{nq, cap, depth, prm->max_depth};
+            if (perlin_lds)
+                hipLaunchKernelGGL((k_shade<true>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals);
+            else
+                hipLaunchKernelGGL((k_shade<false>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals);
+            n_trace_launches += 2;
+        }
+        if (time_depths && sl == 0) {
+            RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)n_depths], st));
+            ctx->timed_depths = n_depths;
+            ctx->timed_rays.assign((size_t)n_depths, 0ull);
+            std::vector<uint32_t> hc((size_t)(n_depths + 1) * nq);
+            RT_HIP(ctx, hipMemcpyAsync(hc.data(), counts, hc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            RT_HIP(ctx, hipStreamSynchronize(st));
+            for (int d = 0; d < n_depths; ++d)
+                for (uint32_t k = 0; k < nq; ++k) ctx->timed_rays[(size_t)d] += hc[(size_t)d * nq + k];
         }
         RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl + 1], st));
         hipLaunchKernelGGL(k_resolve, dim3((npix + 255u) / 256u), dim3(256), 0, st, rad, acc, npix, sc);
-        hipLaunchKernelGGL(k_accum_counts, dim3((n_depths + 63) / 64), dim3(64), 0, st, counts, nq, (uint32_t)n_depths, totals + 2);
+        hipLaunchKernelGGL(k_accum_counts, dim3((unsigned)n_depths), dim3(256), 0, st, counts, nq, (uint32_t)n_depths, totals + 2);
     }
     hipLaunchKernelGGL(k_finalize, dim3((npix + 255u) / 256u), dim3(256), 0, st, acc, (float*)d_out_rgb_f32,
                        (uint8_t*)d_out_rgb8, nx, rows, spp);
@@ -490,6 +531,21 @@ int rt_render(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, float* out_r
     return RT_OK;
 }
 
+int rt_get_depth_timings(RtCtx* ctx, uint32_t max_n, float* isect_ms, float* shade_ms, uint64_t* rays) {
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const int n = std::min<int>(ctx->timed_depths, (int)max_n);
+    for (int d = 0; d < n; ++d) {
+        float a_ms = 0.f, b_ms = 0.f;
+        RT_HIP(ctx, hipEventElapsedTime(&a_ms, ctx->depth_events[2 * (size_t)d], ctx->depth_events[2 * (size_t)d + 1]));
+        RT_HIP(ctx, hipEventElapsedTime(&b_ms, ctx->depth_events[2 * (size_t)d + 1], ctx->depth_events[2 * (size_t)d + 2]));
+        if (isect_ms) isect_ms[d] = a_ms;
+        if (shade_ms) shade_ms[d] = b_ms;
+        if (rays) rays[d] = ctx->timed_rays[(size_t)d];
+    }
+    return n;
+}
+
 int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
     if (!ctx) return RT_ERR_INVALID;
     if (!ctx->has_scene) return fail(ctx, RT_ERR_STATE, "rt_debug_bounce: no scene uploaded");
@@ -513,7 +569,7 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
     const bool use_bvh = ctx->use_bvh && !(io->flags & RT_FLAG_BRUTE_FORCE);
     if (use_bvh) {
         hipLaunchKernelGGL((k_debug_bounce<RT_BVH_BLOCK, true>), dim3((unsigned)((n + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK)),
-                           dim3(RT_BVH_BLOCK), ctx->bvh_lds, st, ctx->ds, (uint32_t)n, (int)io->depth, base + off_o, base + off_d,
+                           dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, (uint32_t)n, (int)io->depth, base + off_o, base + off_d,
                            (const uint32_t*)(base + off_key), (int*)(base + off_hit), base + off_t, base + off_rad, base + off_att,
                            base + off_so, base + off_sd, (uint8_t*)(base + off_alive));
     } else {

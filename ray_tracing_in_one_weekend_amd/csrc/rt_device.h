@@ -204,9 +204,15 @@ struct DevScene {
 // ---------------------------------------------------------------------------------------------
 // texture.rs
 // ---------------------------------------------------------------------------------------------
-__device__ inline float perlin_noise(const DevScene& sc, uint32_t set, V3 p) { // texture.rs:125-146, 93-112
-    const float4* rv = sc.perlin_vec + (size_t)set * 256;
-    const uint8_t* px = sc.perlin_perm + (size_t)set * 768;
+// Perlin table sets: `pvec`/`pperm` point either at the HBM copies in DevScene or at the
+// workgroup's LDS copies (k_shade stages them when they fit, see rt_kernels.h).
+struct PerlinTables {
+    const float4* vec;   // [n_sets*256] xyz_
+    const uint8_t* perm; // [n_sets*768] perm_x, perm_y, perm_z
+};
+__device__ inline float perlin_noise(const PerlinTables& pt, uint32_t set, V3 p) { // texture.rs:125-146, 93-112
+    const float4* rv = pt.vec + (size_t)set * 256;
+    const uint8_t* px = pt.perm + (size_t)set * 768;
     const uint8_t* py = px + 256;
     const uint8_t* pz = py + 256;
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
@@ -231,11 +237,11 @@ __device__ inline float perlin_noise(const DevScene& sc, uint32_t set, V3 p) { /
             }
     return accum;
 }
-__device__ inline float perlin_turb(const DevScene& sc, uint32_t set, V3 p) { // texture.rs:115-124
+__device__ inline float perlin_turb(const PerlinTables& pt, uint32_t set, V3 p) { // texture.rs:115-124
     float accum = 0.0f;
     float w = 1.0f;
     for (int it = 0; it < 7; ++it) {
-        accum += w * perlin_noise(sc, set, p);
+        accum += w * perlin_noise(pt, set, p);
         p = p * 2.0f;
         w *= 0.5f;
     }
@@ -253,7 +259,7 @@ __device__ inline V3 image_value(const DevScene& sc, uint32_t img, V2 uv, uint32
     return v3(t.x, t.y, t.z);
 }
 // `on` = outward unit normal of the hit sphere, from which rec.uv is derived lazily (hitable.rs:98)
-__device__ inline V3 texture_value(const DevScene& sc, uint32_t tex, V3 on, V3 p, uint32_t& n_fetch) {
+__device__ inline V3 texture_value(const DevScene& sc, const PerlinTables& pt, uint32_t tex, V3 on, V3 p, uint32_t& n_fetch) {
     TexRec tr = sc.texs[tex];
     switch (tr.type) {
     case 0: // ConstantTex texture.rs:19-23
@@ -263,7 +269,7 @@ __device__ inline V3 texture_value(const DevScene& sc, uint32_t tex, V3 on, V3 p
         return sines < 0.0f ? v3(tr.c0r, tr.c0g, tr.c0b) : v3(tr.c1r, tr.c1g, tr.c1b);
     }
     case 2: { // PerlinTex texture.rs:164-168
-        float s = sinf(10.0f * perlin_turb(sc, tr.aux, p) + tr.scale * p.z);
+        float s = sinf(10.0f * perlin_turb(pt, tr.aux, p) + tr.scale * p.z);
         return (s + 1.0f) * 0.5f * splat(1.0f);
     }
     default: // ImageTex
@@ -367,7 +373,8 @@ struct Bounce {
 // main.rs:44-58 for one segment whose closest hit is already known.
 // hit < 0: miss -> sky.  Otherwise rebuild the HitRecord (hitable.rs:93-99) and run
 // emitted + scatter of the material (material.rs, pbr.rs).
-__device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float t, Rng& rng, uint32_t& n_fetch) {
+__device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro, V3 rd, int hit, float t, Rng& rng,
+                               uint32_t& n_fetch) {
     Bounce out;
     out.radiance = splat(0.0f);
     out.attenuation = splat(1.0f);
@@ -386,7 +393,7 @@ __device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float 
     MatRec m = sc.mats[sc.sph_mat[hit]];
     switch (m.type) {
     case 0: // Emission material.rs:21-28
-        out.radiance = texture_value(sc, m.tex0, on, p, n_fetch);
+        out.radiance = texture_value(sc, pt, m.tex0, on, p, n_fetch);
         return out;
     case 1: { // Diffuse material.rs:35-46
         V3 sd = n + normalize(random_in_unit_sphere(rng));
@@ -394,7 +401,7 @@ __device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float 
         if (fabsf(sd.x) < eps && fabsf(sd.y) < eps && fabsf(sd.z) < eps) sd = n; // math.rs:8-11
         out.o = offset_hit_point(p, n);
         out.d = normalize(sd);
-        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch);
+        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch);
         out.alive = true;
         return out;
     }
@@ -421,7 +428,7 @@ __device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float 
     case 5: { // Isotropic material.rs:103-113
         out.o = p;
         out.d = normalize(random_in_unit_sphere(rng));
-        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch);
+        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch);
         out.alive = true;
         return out;
     }
@@ -439,7 +446,7 @@ __device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float 
     float n_dot_o = dot(n, dir_o);
     switch (m.type) {
     case 2: // Lambert material.rs:56
-        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch) * 2.0f * dot(n, dir_o);
+        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch) * 2.0f * dot(n, dir_o);
         break;
     case 6: { // OrenNayar pbr.rs:21-39
         float cos_i = fabsf(dot(n, rd));
@@ -459,7 +466,7 @@ __device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float 
             tan_beta = sin_o / cos_o;
         }
         float w = a + b * max_cos * sin_alpha * tan_beta;
-        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch) * w * 2.0f * cos_o;
+        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch) * w * 2.0f * cos_o;
         break;
     }
     case 7: { // BurleyDiffuse pbr.rs:54-66
@@ -469,7 +476,7 @@ __device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float 
         float fv = schlick_fresnel(n_dot_i);
         float fd90 = 0.5f + 2.0f * h_dot_o * h_dot_o * m.p0;
         float fd = lerpf(1.0f, fd90, fl) * lerpf(1.0f, fd90, fv);
-        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch) * fd * 2.0f * n_dot_o;
+        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch) * fd * 2.0f * n_dot_o;
         break;
     }
     case 8: { // RoughPlastic pbr.rs:164-186
@@ -477,8 +484,8 @@ __device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float 
         float h_dot_i = dot(h, -rd);
         float h_dot_o = dot(h, dir_o);
         float n_dot_h = dot(n, h);
-        V3 kd = texture_value(sc, m.tex1, on, p, n_fetch);
-        V3 ks = texture_value(sc, m.tex0, on, p, n_fetch);
+        V3 kd = texture_value(sc, pt, m.tex1, on, p, n_fetch);
+        V3 ks = texture_value(sc, pt, m.tex0, on, p, n_fetch);
         float roughness = clampf(m.p0, 0.01f, 1.0f);
         float eta = m.p1;
         float f_o = fresnel_dielectric_2(h_dot_o, eta);
@@ -501,14 +508,14 @@ __device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float 
         float fss_wi = lerpf(1.0f, fss90, fi);
         float fss_wo = lerpf(1.0f, fss90, fo);
         float fss = 1.25f * (fss_wi * fss_wo * (1.0f / (n_dot_i + n_dot_o) - 0.5f) + 0.5f);
-        out.attenuation = texture_value(sc, m.tex0, on, p, n_fetch) * lerpf(fd, fss, m.p1) * 2.0f * n_dot_o;
+        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch) * lerpf(fd, fss, m.p1) * 2.0f * n_dot_o;
         break;
     }
     case 10: { // DisneyMetal pbr.rs:236-275
         V3 h = normalize(dir_o - rd);
         float h_dot_o = dot(h, dir_o);
         float n_dot_h = dot(n, h);
-        V3 albedo = texture_value(sc, m.tex0, on, p, n_fetch);
+        V3 albedo = texture_value(sc, pt, m.tex0, on, p, n_fetch);
         V3 fm = lerp3(albedo, splat(1.0f), schlick_fresnel(h_dot_o));
         const float alpha_min = 0.0001f;
         float dm, gm;
@@ -535,7 +542,7 @@ __device__ inline Bounce shade(const DevScene& sc, V3 ro, V3 rd, int hit, float 
     case 11: { // DisneySheen pbr.rs:290-305
         V3 h = normalize(dir_o - rd);
         float h_dot_o = dot(h, dir_o);
-        V3 albedo = texture_value(sc, m.tex0, on, p, n_fetch);
+        V3 albedo = texture_value(sc, pt, m.tex0, on, p, n_fetch);
         float luminance = dot(v3(0.3f, 0.6f, 0.1f), albedo);
         V3 c_tint = luminance > 0.0f ? albedo / luminance : splat(1.0f);
         V3 c_sheen = lerp3(splat(1.0f), c_tint, m.p0);

@@ -1,20 +1,27 @@
 // rt_kernels.h — the wavefront (ray-queue) kernels for gfx950.
 //
-//   k_gen_primary  : main.rs:86-94 + camera.rs:40-46, one lane per (pixel, sample) of a slice
-//   k_trace_shade  : main.rs:44-58 for every live ray of one depth: closest hit against the
-//                    LDS-staged sphere list (hitable.rs:75-102,117-132), emitted + scatter
-//                    (material.rs, pbr.rs, texture.rs), wave64 ballot compaction of survivors
-//   k_resolve      : main.rs:95-98 sample sum in sample order
-//   k_finalize     : main.rs:98-105,127 /spp, gamma 2, *255.99 as u8, vertical flip
+//   k_gen_primary    : main.rs:86-94 + camera.rs:40-46, one lane per (pixel, sample) of a slice
+//   k_intersect      : main.rs:44 world.hit(..) for every queued ray of one depth: closest hit by
+//                      traversing the LDS-resident sphere BVH (results == HitableList::hit,
+//                      hitable.rs:117-132); persistent lanes refill from the queue as they finish
+//   k_intersect_list : the same by the plain list walk over LDS tiles of the sphere list
+//                      (RT_FLAG_BRUTE_FORCE, and scenes whose BVH does not fit LDS)
+//   k_shade          : main.rs:45-58: emitted + scatter (material.rs, pbr.rs, texture.rs), sky on
+//                      a miss, radiance retirement, wave64 ballot compaction of the survivors
+//   k_resolve        : main.rs:95-98 sample sum in sample order
+//   k_finalize       : main.rs:98-105,127 /spp, gamma 2, *255.99 as u8, vertical flip
 //
 // Ray queue layout in HBM ("SoA of float4", 48 B per ray, 16 B per lane per load so that one
-// wave instruction moves 1 KiB contiguous):
+// wave instruction moves 1 KiB contiguous), plus an 8 B hit record per ray between the kernels:
 //   qa[i] = (o.x, o.y, o.z, slot)   slot = path slot of the slice = s_local * npix + pixel_local
 //   qb[i] = (d.x, d.y, d.z, k0)     (k0,k1) = per-path RNG key
 //   qc[i] = (T.x, T.y, T.z, k1)     T = path throughput
-// The queue is split into `nq` sub-queues (shards) of capacity `cap` rays; a workgroup reads
-// shard q = blockIdx % nq and appends survivors to shard q of the output queue, so that the
-// append counter is sharded nq ways (one device-scope atomic per wave per chunk).
+//   qh[i] = (t, sphere index)       written by k_intersect, read by k_shade
+// The queue is cut into `nq` shards of capacity `cap` rays.  Shard q is read and appended to by
+// exactly ONE workgroup per kernel (k_shade: workgroup q; k_intersect: workgroup q % gridDim), so
+// queue positions come from an LDS counter: the bounce loop issues no global atomics at all.
+// (One device-scope atomic per wave on 32 shared counters cost 2x in k_shade: the waves sat in
+// s_waitcnt for the returned slot index, profiles/round1.)
 #pragma once
 #include "rt_device.h"
 
@@ -43,17 +50,19 @@ __device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t
 }
 
 // One lane per primary ray of the slice.  idx = s_local * npix + pixel_local, so consecutive
-// lanes are consecutive pixels of a row (coherent first hit).
+// lanes are consecutive pixels of a row (coherent first hit).  Chunks of 256 rays are dealt
+// round-robin to the queue shards, so every shard holds a lattice of image locations.
 __global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q, uint32_t* __restrict__ counts) {
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     // block 0 publishes the per-shard ray counts of depth 0 (closed form of the mapping below)
-    if (blockIdx.x == 0 && threadIdx.x < gp.nq) {
+    if (blockIdx.x == 0) {
         const uint32_t nchunks = (gp.n_rays + 255u) / 256u;
-        const uint32_t sq = threadIdx.x;
-        uint32_t nc = sq < nchunks ? (nchunks - sq + gp.nq - 1u) / gp.nq : 0u;
-        uint32_t cnt = nc * 256u;
-        if (nc && ((nchunks - 1u) % gp.nq) == sq) cnt -= nchunks * 256u - gp.n_rays;
-        counts[sq] = cnt;
+        for (uint32_t sq = threadIdx.x; sq < gp.nq; sq += 256u) {
+            uint32_t nc = sq < nchunks ? (nchunks - sq + gp.nq - 1u) / gp.nq : 0u;
+            uint32_t cnt = nc * 256u;
+            if (nc && ((nchunks - 1u) % gp.nq) == sq) cnt -= nchunks * 256u - gp.n_rays;
+            counts[sq] = cnt;
+        }
     }
     if (idx >= gp.n_rays) return;
     const uint32_t s_local = idx / gp.npix;
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q, uint
 // address (broadcast, conflict-free).
 #define RT_SPHERE_TILE 2048u
 
-// Closest hit over the whole list, HitableList::hit order and acceptance rule
+// Closest hit over a tile of the list, HitableList::hit order and acceptance rule
 // (hitable.rs:117-132: t_max shrinks to the closest so far; a root equal to t_max is accepted).
 __device__ __forceinline__ void closest_hit_tile(const float4* s_geo, uint32_t n, uint32_t base, V3 o, V3 d, float a,
                                                  float& tbest, int& hit) {
@@ -99,172 +108,300 @@ __device__ __forceinline__ void closest_hit_tile(const float4* s_geo, uint32_t n
     }
 }
 
-struct TraceParams {
-    uint32_t nq, cap;
-    int depth, max_depth;
+#define RT_BVH_BLOCK 1024 // threads per workgroup of k_intersect (one LDS copy of the tree)
+#define RT_BVH_MAX_DEPTH 64u
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 16 // a wave refills from the queue when at least this many lanes are idle
+#endif
+#define RT_ISECT_MAX_SHARDS 4u  // queue shards per k_intersect workgroup
+
+// LDS carve of k_intersect: node arrays A,B,C,D (16 B per node each), sphere list (16 B each),
+// the per-lane traversal stack laid out [level][thread] (u16, conflict-free), 16 B of counters.
+__host__ __device__ inline size_t bvh_lds_bytes(uint32_t n_nodes, uint32_t n_spheres, uint32_t block, uint32_t depth) {
+    return (size_t)n_nodes * 64u + (size_t)n_spheres * 16u + (size_t)block * (depth ? depth : 1u) * 2u + 16u;
+}
+
+struct BvhLds {
+    const float4* nA;
+    const float4* nB;
+    const float4* nC;
+    const int4* nD;
+    const float4* geo;
+    unsigned short* stack; // this lane's column: stack[level * BLOCK]
 };
 
-#define RT_BVH_STACK 32 // traversal stack entries per lane (u16 each, in LDS)
-#define RT_BVH_BLOCK 1024 // threads per workgroup of the BVH trace kernel (one LDS copy of the tree)
-
-// LDS carve of the BVH trace kernel: node arrays A,B,C,D (16 B per node each), sphere list
-// (16 B each), then the per-lane traversal stack laid out [level][thread] (conflict-free).
-__host__ __device__ inline size_t bvh_lds_bytes(uint32_t n_nodes, uint32_t n_spheres, uint32_t block) {
-    return (size_t)n_nodes * 64u + (size_t)n_spheres * 16u + (size_t)block * RT_BVH_STACK * 2u;
+template <int BLOCK>
+__device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
+    const uint32_t n_nodes = sc.n_bvh_nodes, n_sph = sc.n_spheres;
+    float4* nA = reinterpret_cast<float4*>(smem);
+    float4* nB = nA + n_nodes;
+    float4* nC = nB + n_nodes;
+    int4* nD = reinterpret_cast<int4*>(nC + n_nodes);
+    float4* geo = reinterpret_cast<float4*>(nD + n_nodes);
+    for (uint32_t i = threadIdx.x; i < n_sph; i += BLOCK) geo[i] = sc.sph_geo[i];
+    for (uint32_t i = threadIdx.x; i < n_nodes; i += BLOCK) {
+        nA[i] = sc.bvh_a[i];
+        nB[i] = sc.bvh_b[i];
+        nC[i] = sc.bvh_c[i];
+        nD[i] = sc.bvh_d[i];
+    }
+    return BvhLds{nA, nB, nC, nD, geo, reinterpret_cast<unsigned short*>(geo + n_sph) + threadIdx.x};
 }
 
-// Closest hit by BVH traversal.  Same result as closest_hit_tile over the whole list: the
-// winner is the smallest accepted root, ties go to the larger sphere index (= the later list
-// entry, hitable.rs:122-126 with the `t_max < root` acceptance of hitable.rs:86), whatever the
-// visiting order.  Boxes are padded at build time and the exit distance is widened by a few ulp,
-// so a box is never culled when the exact sphere test could accept.
+// One traversal step of one lane.  `cur` >= 0: inner node — both child boxes come with the node,
+// slab-test them against [0, tbest], descend into the nearer hit child and push the other;
+// `cur` < 0: sphere ~cur — exact Sphere::hit roots (hitable.rs:75-91).  Returns true when the
+// traversal of this ray has finished.
+//
+// The winner is the smallest accepted root with ties to the larger sphere index, i.e. exactly
+// what the list walk of hitable.rs:117-132 returns (`t_max < root` rejects, so an equal root of a
+// later sphere replaces an earlier one), independent of the visiting order.  Boxes are padded at
+// build time (rt_bvh.h) and entry/exit distances are widened by 2e-6 relative, so a box is never
+// culled when the exact test could accept the sphere inside it.
 template <int BLOCK>
-__device__ __forceinline__ void closest_hit_bvh(const float4* nA, const float4* nB, const float4* nC, const int4* nD,
-                                                const float4* s_geo, unsigned short* stack, V3 o, V3 d, float a,
-                                                float& tbest, int& hit) {
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-    int sp = 0;
-    int cur = 0; // root = inner node 0
+__device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float a, int& cur,
+                                         int& sp, float& tbest, int& hit) {
+    if (cur >= 0) {
+        const float4 A = L.nA[cur], B = L.nB[cur], C = L.nC[cur];
+        const int4 D = L.nD[cur];
+        // left child box: min (A.x, A.y, A.z) max (A.w, B.x, B.y)
+        float x0 = (A.x - o.x) * ix, x1 = (A.w - o.x) * ix;
+        float y0 = (A.y - o.y) * iy, y1 = (B.x - o.y) * iy;
+        float z0 = (A.z - o.z) * iz, z1 = (B.y - o.z) * iz;
+        const float tnl = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+        const float tfl = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        // right child box: min (B.z, B.w, C.x) max (C.y, C.z, C.w)
+        x0 = (B.z - o.x) * ix, x1 = (C.y - o.x) * ix;
+        y0 = (B.w - o.y) * iy, y1 = (C.z - o.y) * iy;
+        z0 = (C.x - o.z) * iz, z1 = (C.w - o.z) * iz;
+        const float tnr = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+        const float tfr = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const bool hl = tnl * 0.999998f <= fminf(tfl * 1.000002f, tbest) && D.x != (int)0x80000000;
+        const bool hr = tnr * 0.999998f <= fminf(tfr * 1.000002f, tbest) && D.y != (int)0x80000000;
+        if (hl && hr) {
+            const bool left_first = tnl <= tnr;
+            L.stack[sp * BLOCK] = (unsigned short)(left_first ? D.y : D.x);
+            ++sp;
+            cur = left_first ? D.x : D.y;
+            return false;
+        }
+        if (hl) {
+            cur = D.x;
+            return false;
+        }
+        if (hr) {
+            cur = D.y;
+            return false;
+        }
+    } else {
+        const int s = ~cur;
+        float th;
+        // candidate root of this sphere (independent of tbest), then the order-independent accept
+        if (sphere_root(L.geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th) && (th < tbest || (th == tbest && s > hit))) {
+            tbest = th;
+            hit = s;
+        }
+    }
+    if (sp == 0) return true;
+    --sp;
+    cur = (int)(short)L.stack[sp * BLOCK];
+    return false;
+}
+
+struct IntersectParams {
+    uint32_t nq, cap;
+};
+
+// Closest hit for every queued ray of the shards q = blockIdx.x, blockIdx.x + gridDim.x, ...
+// Persistent lanes: a lane whose traversal has finished writes its hit record and, once enough
+// lanes of the wave are idle, the wave claims that many fresh rays from the workgroup's LDS work
+// counter (the shards of the workgroup are concatenated into one virtual index space).  With no
+// shading code the kernel needs ~40 VGPRs: two 1024-thread workgroups (8 waves per SIMD) share a
+// CU and hide each other's dependent LDS node fetches.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* __restrict__ qa,
+                                                     const float4* __restrict__ qb, float2* __restrict__ qh,
+                                                     const uint32_t* __restrict__ in_counts, IntersectParams ip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // virtual index space over this workgroup's shards (at most RT_ISECT_MAX_SHARDS, host-checked)
+    uint32_t pre[RT_ISECT_MAX_SHARDS + 1];
+    pre[0] = 0;
+    uint32_t n_my = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < RT_ISECT_MAX_SHARDS; ++k) {
+        const uint32_t q = blockIdx.x + k * gridDim.x;
+        const uint32_t c = q < ip.nq ? in_counts[q] : 0u;
+        pre[k + 1] = pre[k] + c;
+        if (q < ip.nq) n_my = k + 1;
+    }
+    const uint32_t total = pre[RT_ISECT_MAX_SHARDS];
+    if (total == 0) return; // block-uniform
+    const BvhLds L = stage_bvh<BLOCK>(sc, smem);
+    uint32_t* s_work = reinterpret_cast<uint32_t*>(smem + bvh_lds_bytes(sc.n_bvh_nodes, sc.n_spheres, BLOCK, sc.bvh_depth) - 16u);
+    if (threadIdx.x == 0) *s_work = 0u;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool no_geometry = sc.n_spheres == 0u;
+    bool exhausted = false; // wave-uniform: the workgroup has no unclaimed rays left
+    bool has = false;
+    V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
+    float ix = 0.f, iy = 0.f, iz = 0.f, a = 1.0f, tbest = RT_FLT_MAX;
+    int hit = -1, cur = 0, sp = 0;
+    size_t pos = 0;
     for (;;) {
-        if (cur >= 0) {
-            const float4 A = nA[cur], B = nB[cur], C = nC[cur];
-            const int4 D = nD[cur];
-            // left child box: min (A.x, A.y, A.z) max (A.w, B.x, B.y)
-            float x0 = (A.x - o.x) * ix, x1 = (A.w - o.x) * ix;
-            float y0 = (A.y - o.y) * iy, y1 = (B.x - o.y) * iy;
-            float z0 = (A.z - o.z) * iz, z1 = (B.y - o.z) * iz;
-            float tnl = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-            float tfl = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-            // right child box: min (B.z, B.w, C.x) max (C.y, C.z, C.w)
-            x0 = (B.z - o.x) * ix, x1 = (C.y - o.x) * ix;
-            y0 = (B.w - o.y) * iy, y1 = (C.z - o.y) * iy;
-            z0 = (C.x - o.z) * iz, z1 = (C.w - o.z) * iz;
-            float tnr = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-            float tfr = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-            const bool hl = tnl * 0.999998f <= fminf(tfl * 1.000002f, tbest) && D.x != (int)0x80000000;
-            const bool hr = tnr * 0.999998f <= fminf(tfr * 1.000002f, tbest) && D.y != (int)0x80000000;
-            if (hl && hr) {
-                const bool left_first = tnl <= tnr;
-                stack[sp * BLOCK] = (unsigned short)(left_first ? D.y : D.x);
-                ++sp;
-                cur = left_first ? D.x : D.y;
-            } else if (hl) {
-                cur = D.x;
-            } else if (hr) {
-                cur = D.y;
-            } else {
-                if (sp == 0) break;
-                --sp;
-                cur = (int)(short)stack[sp * BLOCK];
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle >= RT_REFILL_MIN && !exhausted) {
+            uint32_t v0 = 0;
+            if (lane == 0) v0 = atomicAdd(s_work, n_idle); // LDS atomic: claim n_idle rays
+            v0 = __builtin_amdgcn_readfirstlane(v0);
+            if (v0 + n_idle >= total) exhausted = true;
+            const uint32_t v =
+                v0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (!has && v < total) {
+                uint32_t k = 0;
+#pragma unroll
+                for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) k += (t < n_my && v >= pre[t]) ? 1u : 0u;
+                uint32_t off = v;
+#pragma unroll
+                for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) off = (k == t) ? v - pre[t] : off;
+                pos = (size_t)(blockIdx.x + k * gridDim.x) * ip.cap + off;
+                const float4 ra = qa[pos], rb = qb[pos];
+                o = v3(ra.x, ra.y, ra.z);
+                d = v3(rb.x, rb.y, rb.z);
+                ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+                a = length_squared(d); // hitable.rs:77
+                tbest = RT_FLT_MAX;
+                hit = -1;
+                cur = 0;
+                sp = 0;
+                has = !no_geometry;
+                if (no_geometry) qh[pos] = make_float2(RT_FLT_MAX, __int_as_float(-1));
             }
-        } else {
-            const int s = ~cur;
-            float th;
-            // candidate root of this sphere (independent of tbest), then order-independent accept
-            if (sphere_root(s_geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th) && (th < tbest || (th == tbest && s > hit))) {
-                tbest = th;
-                hit = s;
-            }
-            if (sp == 0) break;
-            --sp;
-            cur = (int)(short)stack[sp * BLOCK];
+        }
+        if (!__any(has)) {
+            if (exhausted) break;
+            continue;
+        }
+        if (has && bvh_step<BLOCK>(L, o, d, ix, iy, iz, a, cur, sp, tbest, hit)) {
+            qh[pos] = make_float2(tbest, __int_as_float(hit));
+            has = false;
         }
     }
 }
 
-// One chunk-loop body shared by both closest-hit strategies: shade, retire or compact.
-template <int BLOCK, bool USE_BVH>
-__global__ __launch_bounds__(BLOCK) void k_trace_shade(DevScene sc, Queue qin, Queue qout,
-                                                       const uint32_t* __restrict__ in_counts,
-                                                       uint32_t* __restrict__ out_counts, float* __restrict__ rad,
-                                                       TraceParams tp, unsigned long long* __restrict__ stats) {
+// List-walk closest hit: one workgroup per shard, sphere list streamed through LDS tiles.
+__global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float4* __restrict__ qa,
+                                                        const float4* __restrict__ qb, float2* __restrict__ qh,
+                                                        const uint32_t* __restrict__ in_counts, IntersectParams ip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t q = blockIdx.x % tp.nq;
-    const uint32_t bq = blockIdx.x / tp.nq;
-    const uint32_t nbq = gridDim.x / tp.nq;
+    float4* s_geo = reinterpret_cast<float4*>(smem);
+    const uint32_t q = blockIdx.x;
     const uint32_t count = in_counts[q];
-    if (bq * BLOCK >= count) return; // block-uniform: nothing queued for this workgroup
+    if (count == 0) return;
     const uint32_t n_sph = sc.n_spheres;
-    // LDS carve
-    float4* nA = reinterpret_cast<float4*>(smem);
-    float4* nB = nA + (USE_BVH ? sc.n_bvh_nodes : 0u);
-    float4* nC = nB + (USE_BVH ? sc.n_bvh_nodes : 0u);
-    int4* nD = reinterpret_cast<int4*>(nC + (USE_BVH ? sc.n_bvh_nodes : 0u));
-    float4* s_geo = reinterpret_cast<float4*>(nD + (USE_BVH ? sc.n_bvh_nodes : 0u));
-    unsigned short* stack = reinterpret_cast<unsigned short*>(s_geo + (USE_BVH ? n_sph : 0u)) + threadIdx.x;
-    const bool single_tile = USE_BVH || n_sph <= RT_SPHERE_TILE;
+    const bool single_tile = n_sph <= RT_SPHERE_TILE;
     if (single_tile) {
-        for (uint32_t i = threadIdx.x; i < n_sph; i += BLOCK) s_geo[i] = sc.sph_geo[i];
-        if (USE_BVH) {
-            for (uint32_t i = threadIdx.x; i < sc.n_bvh_nodes; i += BLOCK) {
-                nA[i] = sc.bvh_a[i];
-                nB[i] = sc.bvh_b[i];
-                nC[i] = sc.bvh_c[i];
-                nD[i] = sc.bvh_d[i];
-            }
-        }
+        for (uint32_t i = threadIdx.x; i < n_sph; i += 256u) s_geo[i] = sc.sph_geo[i];
         __syncthreads();
     }
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t n_fetch = 0, n_bad = 0;
-    const size_t qbase = (size_t)q * tp.cap;
-    for (uint32_t base = bq * BLOCK; base < count; base += nbq * BLOCK) {
+    const size_t qbase = (size_t)q * ip.cap;
+    for (uint32_t base = 0; base < count; base += 256u) {
         const uint32_t i = base + threadIdx.x;
         const bool active = i < count;
-        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = make_float4(0.f, 0.f, 1.f, 0.f), rc = ra;
+        V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
         if (active) {
-            ra = qin.a[qbase + i];
-            rb = qin.b[qbase + i];
-            rc = qin.c[qbase + i];
+            const float4 ra = qa[qbase + i], rb = qb[qbase + i];
+            o = v3(ra.x, ra.y, ra.z);
+            d = v3(rb.x, rb.y, rb.z);
         }
-        const V3 o = v3(ra.x, ra.y, ra.z), d = v3(rb.x, rb.y, rb.z), T = v3(rc.x, rc.y, rc.z);
-        const uint32_t slot = __float_as_uint(ra.w);
-        // closest hit: main.rs:44 world.hit(&r, 1e-3, f32::MAX, &mut rec)
         float tbest = RT_FLT_MAX;
         int hit = -1;
-        const float a = length_squared(d); // hitable.rs:77
-        if (USE_BVH) {
-            if (active && n_sph) closest_hit_bvh<BLOCK>(nA, nB, nC, nD, s_geo, stack, o, d, a, tbest, hit);
-        } else if (single_tile) {
+        const float a = length_squared(d);
+        if (single_tile) {
             closest_hit_tile(s_geo, n_sph, 0u, o, d, a, tbest, hit);
         } else {
             for (uint32_t t0 = 0; t0 < n_sph; t0 += RT_SPHERE_TILE) {
                 const uint32_t n = min(RT_SPHERE_TILE, n_sph - t0);
                 __syncthreads();
-                for (uint32_t k = threadIdx.x; k < n; k += BLOCK) s_geo[k] = sc.sph_geo[t0 + k];
+                for (uint32_t k = threadIdx.x; k < n; k += 256u) s_geo[k] = sc.sph_geo[t0 + k];
                 __syncthreads();
                 closest_hit_tile(s_geo, n, t0, o, d, a, tbest, hit);
             }
         }
+        if (active) qh[qbase + i] = make_float2(tbest, __int_as_float(hit));
+    }
+}
+
+struct ShadeParams {
+    uint32_t nq, cap;
+    int depth, max_depth;
+};
+
+// Shading half of the step: workgroup q owns shard q (reads it, appends survivors to shard q of
+// the output queue through an LDS counter, publishes the new count with a plain store).
+// PERLIN_LDS: the Perlin gradient and permutation tables (texture.rs:53-58; 4.75 KB per set) are
+// staged into LDS.
+#define RT_PERLIN_LDS_MAX_SETS 4u
+template <bool PERLIN_LDS>
+__global__ __launch_bounds__(256) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
+                                               const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,
+                                               float* __restrict__ rad, ShadeParams tp,
+                                               unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t q = blockIdx.x;
+    const uint32_t count = in_counts[q];
+    if (count == 0) return; // out_counts[q] stays 0 (cleared per slice)
+    uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);
+    PerlinTables pt{sc.perlin_vec, sc.perlin_perm};
+    if (PERLIN_LDS) {
+        float4* lv = reinterpret_cast<float4*>(smem + 16);
+        uint8_t* lp = reinterpret_cast<uint8_t*>(lv + sc.n_perlin * 256u);
+        for (uint32_t i = threadIdx.x; i < sc.n_perlin * 256u; i += 256u) lv[i] = sc.perlin_vec[i];
+        for (uint32_t i = threadIdx.x; i < sc.n_perlin * 768u; i += 256u) lp[i] = sc.perlin_perm[i];
+        pt.vec = lv;
+        pt.perm = lp;
+    }
+    if (threadIdx.x == 0) *s_out = 0u;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n_fetch = 0, n_bad = 0;
+    const size_t qbase = (size_t)q * tp.cap;
+    for (uint32_t base = 0; base < count; base += 256u) {
+        const uint32_t i = base + threadIdx.x;
         bool alive = false;
-        V3 L = splat(0.0f);
         Bounce bo;
         bo.o = bo.d = bo.attenuation = splat(0.0f);
-        uint32_t k0 = __float_as_uint(rb.w), k1 = __float_as_uint(rc.w);
-        if (active) {
+        V3 T = splat(0.0f);
+        uint32_t slot = 0, k0 = 0, k1 = 0;
+        if (i < count) {
+            const float4 ra = qin.a[qbase + i], rb = qin.b[qbase + i], rc = qin.c[qbase + i];
+            const float2 h = qh[qbase + i];
+            const V3 o = v3(ra.x, ra.y, ra.z), d = v3(rb.x, rb.y, rb.z);
+            T = v3(rc.x, rc.y, rc.z);
+            slot = __float_as_uint(ra.w), k0 = __float_as_uint(rb.w), k1 = __float_as_uint(rc.w);
+            V3 Lr = splat(0.0f);
             if (!near_one(d)) { // main.rs:39 assert!: the reference panics; the path is dropped
                 ++n_bad;
             } else {
                 Rng rng{k0, k1, depth_counter_base(tp.depth)};
-                bo = shade(sc, o, d, hit, tbest, rng, n_fetch);
+                bo = shade(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch);
                 if (bo.alive) {
-                    // survivors of the last traced depth return 0 at main.rs:40-42
-                    alive = tp.depth < tp.max_depth;
+                    alive = tp.depth < tp.max_depth; // survivors of the last depth return 0, main.rs:40-42
                 } else {
-                    L = T * bo.radiance; // L = T_n * (emitted | sky)
+                    Lr = T * bo.radiance; // L = T_n * (emitted | sky)
                 }
             }
             if (!alive) {
                 float* r = rad + (size_t)slot * 3u;
-                r[0] = L.x, r[1] = L.y, r[2] = L.z;
+                r[0] = Lr.x, r[1] = Lr.y, r[2] = Lr.z;
             }
         }
-        // wave64 compaction: ballot + prefix popcount, one atomic per wave to claim queue slots
+        // wave64 compaction: ballot + prefix popcount; the wave claims its slots from the LDS counter
         const unsigned long long mask = __ballot(alive);
         if (mask) {
-            const uint32_t n_alive = (uint32_t)__popcll(mask);
             uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&out_counts[q], n_alive);
+            if (lane == 0) wbase = atomicAdd(s_out, (uint32_t)__popcll(mask));
             wbase = __builtin_amdgcn_readfirstlane(wbase);
             if (alive) {
                 const uint32_t rank =
@@ -277,6 +414,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace_shade(DevScene sc, Queue qin, Q
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) out_counts[q] = *s_out;
     // rare-event counters: one atomic per wave, only when nonzero
     for (int off = 32; off > 0; off >>= 1) {
         n_fetch += __shfl_down(n_fetch, off);
@@ -326,16 +465,20 @@ __global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ acc,
 }
 
 // Sums the per-shard counters of every depth into 64-bit totals (ray statistics).
-__global__ void k_accum_counts(const uint32_t* __restrict__ counts, uint32_t nq, uint32_t n_depths,
-                               unsigned long long* __restrict__ totals) {
-    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_accum_counts(const uint32_t* __restrict__ counts, uint32_t nq, uint32_t n_depths,
+                                                      unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long part[4];
+    const uint32_t d = blockIdx.x;
     if (d >= n_depths) return;
     unsigned long long s = 0;
-    for (uint32_t k = 0; k < nq; ++k) s += counts[(size_t)d * nq + k];
-    totals[d] += s;
+    for (uint32_t k = threadIdx.x; k < nq; k += 256u) s += counts[(size_t)d * nq + k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) totals[d] += part[0] + part[1] + part[2] + part[3];
 }
 
-// Test hook: one bounce for caller-given rays, no compaction (rt_debug_bounce).
+// Test hook: one bounce for caller-given rays, no queues (rt_debug_bounce).
 template <int BLOCK, bool USE_BVH>
 __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n, int depth, const float* __restrict__ in_o,
                                                         const float* __restrict__ in_d, const uint32_t* __restrict__ in_key,
@@ -355,21 +498,14 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
     int hit = -1;
     const float a = length_squared(d);
     if (USE_BVH) {
-        float4* nA = reinterpret_cast<float4*>(smem);
-        float4* nB = nA + sc.n_bvh_nodes;
-        float4* nC = nB + sc.n_bvh_nodes;
-        int4* nD = reinterpret_cast<int4*>(nC + sc.n_bvh_nodes);
-        float4* s_geo = reinterpret_cast<float4*>(nD + sc.n_bvh_nodes);
-        unsigned short* stack = reinterpret_cast<unsigned short*>(s_geo + sc.n_spheres) + threadIdx.x;
-        for (uint32_t k = threadIdx.x; k < sc.n_spheres; k += BLOCK) s_geo[k] = sc.sph_geo[k];
-        for (uint32_t k = threadIdx.x; k < sc.n_bvh_nodes; k += BLOCK) {
-            nA[k] = sc.bvh_a[k];
-            nB[k] = sc.bvh_b[k];
-            nC[k] = sc.bvh_c[k];
-            nD[k] = sc.bvh_d[k];
-        }
+        const BvhLds L = stage_bvh<BLOCK>(sc, smem);
         __syncthreads();
-        if (active && sc.n_spheres) closest_hit_bvh<BLOCK>(nA, nB, nC, nD, s_geo, stack, o, d, a, tbest, hit);
+        if (active && sc.n_spheres) {
+            const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+            int cur = 0, sp = 0;
+            while (!bvh_step<BLOCK>(L, o, d, ix, iy, iz, a, cur, sp, tbest, hit)) {
+            }
+        }
     } else {
         float4* s_geo = reinterpret_cast<float4*>(smem);
         for (uint32_t t0 = 0; t0 < sc.n_spheres; t0 += RT_SPHERE_TILE) {
@@ -383,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
     if (!active) return;
     uint32_t n_fetch = 0;
     Rng rng{in_key[2 * i], in_key[2 * i + 1], depth_counter_base(depth)};
-    Bounce bo = shade(sc, o, d, hit, tbest, rng, n_fetch);
+    Bounce bo = shade(sc, PerlinTables{sc.perlin_vec, sc.perlin_perm}, o, d, hit, tbest, rng, n_fetch);
     out_hit[i] = hit;
     out_t[i] = hit >= 0 ? tbest : 0.0f;
     out_rad[3 * i] = bo.radiance.x, out_rad[3 * i + 1] = bo.radiance.y, out_rad[3 * i + 2] = bo.radiance.z;

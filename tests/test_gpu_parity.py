@@ -145,9 +145,10 @@ def test_bvh_equals_brute_force_on_adversarial_rays(rt, orc, renderer):
     # whole renders agree bit for bit as well
     p = rt.make_params(160, 90, 4, max_depth=50)
     i1, _, s1 = renderer.render(scene.camera, p)
-    p.flags = rt._ffi.FLAG_BRUTE_FORCE
-    i2, _, s2 = renderer.render(scene.camera, p)
-    assert np.array_equal(i1.view(np.uint32), i2.view(np.uint32)) and s1.n_rays == s2.n_rays
+    for flags in (rt._ffi.FLAG_BRUTE_FORCE,):  # list walk
+        p.flags = flags
+        i2, _, s2 = renderer.render(scene.camera, p)
+        assert np.array_equal(i1.view(np.uint32), i2.view(np.uint32)) and s1.n_rays == s2.n_rays
 
 
 def test_render_config1_random_spheres(rt, orc, renderer):
