@@ -39,7 +39,7 @@ struct RtCtx {
     std::vector<void*> scene_allocs;
     // work buffers (grown on demand, reused across calls)
     DevBuf qbuf[6];   // two queues x (a, b, c)
-    DevBuf rad, acc, counts, totals, out_f32, out_u8, dbg, qhit;
+    DevBuf rad, acc, counts, totals, out_f32, out_u8, dbg, qhit, genp;
     std::vector<hipEvent_t> events;
     std::vector<hipEvent_t> depth_events;  // RT_FLAG_TIME_DEPTHS: 2 per depth + 1
     int timed_depths = 0;
@@ -168,7 +168,7 @@ void rt_ctx_destroy(RtCtx* ctx) {
     free_scene(ctx);
     for (auto& b : ctx->qbuf) free_buf(b);
     free_buf(ctx->rad), free_buf(ctx->acc), free_buf(ctx->counts), free_buf(ctx->totals);
-    free_buf(ctx->out_f32), free_buf(ctx->out_u8), free_buf(ctx->dbg), free_buf(ctx->qhit);
+    free_buf(ctx->out_f32), free_buf(ctx->out_u8), free_buf(ctx->dbg), free_buf(ctx->qhit), free_buf(ctx->genp);
     for (auto ev : ctx->events) (void)hipEventDestroy(ev);
     for (auto ev : ctx->depth_events) (void)hipEventDestroy(ev);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -286,6 +286,12 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
 
     HostBvh bvh;
     build_sphere_bvh(geo, RT_BVH_MAX_DEPTH, bvh);
+    std::vector<uint8_t> sclass(s->n_spheres);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const uint32_t m = s->sph_mat[i], ty = s->mat_type[m];
+        const uint32_t tt = (mat_needs_tex0(ty) && s->mat_tex0[m] < s->n_textures) ? s->tex_type[s->mat_tex0[m]] : 0u;
+        sclass[i] = (uint8_t)(1u + ty * 4u + tt); // < RT_NCLASS
+    }
 
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
@@ -299,7 +305,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
         (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
         (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, bvh.a, &ds.bvh_a)) || (rc = upload(ctx, bvh.b, &ds.bvh_b)) ||
-        (rc = upload(ctx, bvh.c, &ds.bvh_c)) || (rc = upload(ctx, bvh.d, &ds.bvh_d))) {
+        (rc = upload(ctx, bvh.c, &ds.bvh_c)) || (rc = upload(ctx, bvh.d, &ds.bvh_d)) || (rc = upload(ctx, sclass, &ds.sph_class))) {
         free_scene(ctx);
         return rc;
     }
@@ -310,7 +316,9 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     ctx->use_bvh = ds.n_spheres > 0 && ds.n_bvh_nodes > 0 && ds.n_bvh_nodes < 32768 && ds.n_spheres <= 32768 &&
                    bvh.depth <= RT_BVH_MAX_DEPTH && ctx->isect_lds <= ctx->lds_limit;
     if (ctx->use_bvh) {
-        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK>),
+        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
+        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
         RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
@@ -363,6 +371,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     uint32_t nq = (uint32_t)ctx->n_cu * 8u;
     if (const char* e = getenv("RTOW_NQ")) nq = (uint32_t)std::max(1, atoi(e)); // experiment knob (scripts/)
     const bool use_bvh = ctx->use_bvh && !(prm->flags & RT_FLAG_BRUTE_FORCE);
+    // depth 0 regenerates the primary ray in both kernels instead of materialising the queue
+    const bool fuse_gen = use_bvh && !getenv("RTOW_NO_FUSE_GEN");
     // k_intersect: as many 1024-thread workgroups per CU as LDS admits (two at <= 64 VGPRs); every
     // workgroup owns nq / isect_grid shards
     const uint32_t isect_wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_limit / std::max<size_t>(ctx->isect_lds, 1)));
@@ -382,6 +392,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     if ((rc = ensure(ctx, ctx->counts, counts_bytes))) return rc;
     const size_t totals_bytes = (size_t)(n_depths + 2) * sizeof(unsigned long long);
     if ((rc = ensure(ctx, ctx->totals, totals_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->genp, sizeof(GenParams)))) return rc;
+    GenParams* gpd = (GenParams*)ctx->genp.p;
     while (ctx->events.size() < 2 * (size_t)n_slices) {
         hipEvent_t ev;
         RT_HIP(ctx, hipEventCreate(&ev));
@@ -398,7 +410,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
 
     const size_t list_lds = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
     const bool perlin_lds = ctx->ds.n_perlin > 0 && ctx->ds.n_perlin <= RT_PERLIN_LDS_MAX_SETS;
-    const size_t shade_lds = 16u + (perlin_lds ? (size_t)ctx->ds.n_perlin * (256u * sizeof(float4) + 768u) : 0u);
+    const size_t shade_lds = shade_lds_bytes(ctx->ds.n_spheres, perlin_lds ? ctx->ds.n_perlin : 0u);
+    if (shade_lds > 64u * 1024u) return fail(ctx, RT_ERR_UNSUPPORTED, "render: scene has too many spheres for the k_shade class table");
 
     RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
     RT_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * 3 * sizeof(float), st));
@@ -433,7 +446,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         gp.s0 = s0;
         gp.n_rays = npix * sc;
         RT_HIP(ctx, hipMemsetAsync(counts, 0, counts_bytes, st));
-        hipLaunchKernelGGL(k_gen_primary, dim3((gp.n_rays + 255u) / 256u), dim3(256), 0, st, gp, Q[0], counts);
+        hipLaunchKernelGGL(k_init_counts, dim3((nq + 255u) / 256u), dim3(256), 0, st, gp, counts, gpd);
+        if (!fuse_gen) hipLaunchKernelGGL(k_gen_primary, dim3((gp.n_rays + 255u) / 256u), dim3(256), 0, st, gp, Q[0]);
         RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl], st));
         for (int depth = 0; depth < n_depths; ++depth) {
             const Queue& qi = Q[depth & 1];
@@ -442,17 +456,25 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             uint32_t* cout = counts + (size_t)(depth + 1) * nq;
             const bool td = time_depths && sl == 0;
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth], st));
-            if (use_bvh)
-                hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds,
-                                   qi.a, qi.b, qhit, cin, ip);
+            const bool gen = fuse_gen && depth == 0;
+            if (use_bvh && gen)
+                hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, true>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds,
+                                   qi.a, qi.b, qhit, cin, ip, gpd);
+            else if (use_bvh)
+                hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, false>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds,
+                                   qi.a, qi.b, qhit, cin, ip, gpd);
             else
                 hipLaunchKernelGGL(k_intersect_list, dim3(nq), dim3(256), list_lds, st, ctx->ds, qi.a, qi.b, qhit, cin, ip);
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth + 1], st));
-            const ShadeParams sp{nq, cap, depth, prm->max_depth};
-            if (perlin_lds)
-                hipLaunchKernelGGL((k_shade<true>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals);
-            else
-                hipLaunchKernelGGL((k_shade<false>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals);
+            // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
+            const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u};
+#define RT_LAUNCH_SHADE(P, G) \
+    hipLaunchKernelGGL((k_shade<P, G>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals, gpd)
+            if (perlin_lds && gen) RT_LAUNCH_SHADE(true, true);
+            else if (perlin_lds) RT_LAUNCH_SHADE(true, false);
+            else if (gen) RT_LAUNCH_SHADE(false, true);
+            else RT_LAUNCH_SHADE(false, false);
+#undef RT_LAUNCH_SHADE
             n_trace_launches += 2;
         }
         if (time_depths && sl == 0) {

@@ -199,6 +199,9 @@ struct DevScene {
     const float4* bvh_b;
     const float4* bvh_c;
     const int4* bvh_d;
+    // shading class of every sphere (1 + material_type*4 + texture_type of tex0; 0 is "miss"):
+    // k_shade sorts the rays of a chunk by class so that a wave runs one material branch
+    const uint8_t* sph_class;
 };
 
 // ---------------------------------------------------------------------------------------------

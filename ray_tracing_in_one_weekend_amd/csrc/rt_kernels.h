@@ -1,6 +1,8 @@
 // rt_kernels.h — the wavefront (ray-queue) kernels for gfx950.
 //
-//   k_gen_primary    : main.rs:86-94 + camera.rs:40-46, one lane per (pixel, sample) of a slice
+//   gen_primary()    : main.rs:86-94 + camera.rs:40-46; at depth 0 k_intersect and k_shade
+//                      regenerate the primary ray from its queue position (no queue traffic);
+//                      k_gen_primary materialises the queue only for the list-walk fallback
 //   k_intersect      : main.rs:44 world.hit(..) for every queued ray of one depth: closest hit by
 //                      traversing the LDS-resident sphere BVH (results == HitableList::hit,
 //                      hitable.rs:117-132); persistent lanes refill from the queue as they finish
@@ -49,22 +51,9 @@ __device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t
     return ((lj / band) * count + id) * band + (lj % band);
 }
 
-// One lane per primary ray of the slice.  idx = s_local * npix + pixel_local, so consecutive
-// lanes are consecutive pixels of a row (coherent first hit).  Chunks of 256 rays are dealt
-// round-robin to the queue shards, so every shard holds a lattice of image locations.
-__global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q, uint32_t* __restrict__ counts) {
-    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
-    // block 0 publishes the per-shard ray counts of depth 0 (closed form of the mapping below)
-    if (blockIdx.x == 0) {
-        const uint32_t nchunks = (gp.n_rays + 255u) / 256u;
-        for (uint32_t sq = threadIdx.x; sq < gp.nq; sq += 256u) {
-            uint32_t nc = sq < nchunks ? (nchunks - sq + gp.nq - 1u) / gp.nq : 0u;
-            uint32_t cnt = nc * 256u;
-            if (nc && ((nchunks - 1u) % gp.nq) == sq) cnt -= nchunks * 256u - gp.n_rays;
-            counts[sq] = cnt;
-        }
-    }
-    if (idx >= gp.n_rays) return;
+// Primary ray of path `idx` of the slice (main.rs:86-94 + camera.rs:40-46).
+// idx = s_local * npix + pixel_local, so consecutive idx are consecutive pixels of a row.
+__device__ __forceinline__ void gen_primary(const GenParams& gp, uint32_t idx, V3& o, V3& d, uint32_t& k0, uint32_t& k1) {
     const uint32_t s_local = idx / gp.npix;
     const uint32_t pl = idx - s_local * gp.npix;
     const uint32_t lj = pl / gp.nx;
@@ -75,20 +64,54 @@ __global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q, uint
     path_key(((uint64_t)gp.seed_hi << 32) | gp.seed_lo, j * gp.nx + i, samp, rng.k0, rng.k1);
     rng.ctr = 0;
     // main.rs:89-90
-    float u = ((float)i + rng.next()) / (float)gp.nx;
-    float v = ((float)j + rng.next()) / (float)gp.ny;
+    const float u = ((float)i + rng.next()) / (float)gp.nx;
+    const float v = ((float)j + rng.next()) / (float)gp.ny;
     // camera.rs:40-46
-    V3 origin = v3(gp.cam_origin[0], gp.cam_origin[1], gp.cam_origin[2]);
-    V3 H = v3(gp.cam_horizontal[0], gp.cam_horizontal[1], gp.cam_horizontal[2]);
-    V3 Vv = v3(gp.cam_vertical[0], gp.cam_vertical[1], gp.cam_vertical[2]);
-    V3 llc = v3(gp.cam_llc[0], gp.cam_llc[1], gp.cam_llc[2]);
-    V3 d = normalize(llc + u * H + v * Vv - origin);
+    const V3 origin = v3(gp.cam_origin[0], gp.cam_origin[1], gp.cam_origin[2]);
+    const V3 H = v3(gp.cam_horizontal[0], gp.cam_horizontal[1], gp.cam_horizontal[2]);
+    const V3 Vv = v3(gp.cam_vertical[0], gp.cam_vertical[1], gp.cam_vertical[2]);
+    const V3 llc = v3(gp.cam_llc[0], gp.cam_llc[1], gp.cam_llc[2]);
+    o = origin;
+    d = normalize(llc + u * H + v * Vv - origin);
+    k0 = rng.k0, k1 = rng.k1;
+}
+
+// Depth-0 queue geometry: chunks of 256 consecutive paths are dealt round-robin to the queue
+// shards (every shard holds a lattice of image locations, so shards stay balanced as paths die).
+//   path idx -> shard (idx/256) % nq, position ((idx/256)/nq)*256 + idx%256     and back:
+__device__ __forceinline__ uint32_t primary_idx_of(uint32_t nq, uint32_t shard, uint32_t pos) {
+    return ((pos >> 8) * nq + shard) * 256u + (pos & 255u);
+}
+// Number of primary rays of each shard (closed form of the mapping above).
+// Also parks the slice's GenParams in HBM for the depth-0 kernels (they read them through a
+// pointer: 24 dwords of kernel arguments would push k_intersect past 80 SGPRs and cost a wave).
+__global__ __launch_bounds__(256) void k_init_counts(GenParams gp, uint32_t* __restrict__ counts,
+                                                     GenParams* __restrict__ gp_dev) {
+    const uint32_t sq = blockIdx.x * 256u + threadIdx.x;
+    if (sq == 0) *gp_dev = gp;
+    if (sq >= gp.nq) return;
+    const uint32_t nchunks = (gp.n_rays + 255u) / 256u;
+    const uint32_t nc = sq < nchunks ? (nchunks - sq + gp.nq - 1u) / gp.nq : 0u;
+    uint32_t cnt = nc * 256u;
+    if (nc && ((nchunks - 1u) % gp.nq) == sq) cnt -= nchunks * 256u - gp.n_rays;
+    counts[sq] = cnt;
+}
+
+// Materialises the primary rays in the queue.  Only the list-walk fallback uses it: on the BVH
+// path k_intersect and k_shade regenerate the ray of depth 0 from its queue position instead
+// (80 instructions twice per path against 48 B written + 80 B read back from HBM).
+__global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= gp.n_rays) return;
+    V3 o, d;
+    uint32_t k0, k1;
+    gen_primary(gp, idx, o, d, k0, k1);
     const uint32_t chunk = idx >> 8;
     const uint32_t sq = chunk % gp.nq;
     const size_t pos = (size_t)sq * gp.cap + (size_t)(chunk / gp.nq) * 256u + (idx & 255u);
-    q.a[pos] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(idx));
-    q.b[pos] = make_float4(d.x, d.y, d.z, __uint_as_float(rng.k0));
-    q.c[pos] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.k1));
+    q.a[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(idx));
+    q.b[pos] = make_float4(d.x, d.y, d.z, __uint_as_float(k0));
+    q.c[pos] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(k1));
 }
 
 // LDS tile of the sphere list: (cx, cy, cz, r) as float4, read by every lane at the same
@@ -111,7 +134,8 @@ __device__ __forceinline__ void closest_hit_tile(const float4* s_geo, uint32_t n
 #define RT_BVH_BLOCK 1024 // threads per workgroup of k_intersect (one LDS copy of the tree)
 #define RT_BVH_MAX_DEPTH 64u
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 16 // a wave refills from the queue when at least this many lanes are idle
+#define RT_REFILL_MIN 48 // a wave refills from the queue when at least this many lanes are idle
+                         // (measured: 8 -> 16.9 ms, 16 -> 15.6, 48 -> 14.7, 64 -> 16.0 per 337 M rays)
 #endif
 #define RT_ISECT_MAX_SHARDS 4u  // queue shards per k_intersect workgroup
 
@@ -218,10 +242,12 @@ struct IntersectParams {
 // counter (the shards of the workgroup are concatenated into one virtual index space).  With no
 // shading code the kernel needs ~40 VGPRs: two 1024-thread workgroups (8 waves per SIMD) share a
 // CU and hide each other's dependent LDS node fetches.
-template <int BLOCK>
+// GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
+template <int BLOCK, bool GEN>
 __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* __restrict__ qa,
                                                      const float4* __restrict__ qb, float2* __restrict__ qh,
-                                                     const uint32_t* __restrict__ in_counts, IntersectParams ip) {
+                                                     const uint32_t* __restrict__ in_counts, IntersectParams ip,
+                                                     const GenParams* __restrict__ gpd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // virtual index space over this workgroup's shards (at most RT_ISECT_MAX_SHARDS, host-checked)
     uint32_t pre[RT_ISECT_MAX_SHARDS + 1];
@@ -265,10 +291,16 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
                 uint32_t off = v;
 #pragma unroll
                 for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) off = (k == t) ? v - pre[t] : off;
-                pos = (size_t)(blockIdx.x + k * gridDim.x) * ip.cap + off;
-                const float4 ra = qa[pos], rb = qb[pos];
-                o = v3(ra.x, ra.y, ra.z);
-                d = v3(rb.x, rb.y, rb.z);
+                const uint32_t shard = blockIdx.x + k * gridDim.x;
+                pos = (size_t)shard * ip.cap + off;
+                if (GEN) {
+                    uint32_t k0, k1;
+                    gen_primary(*gpd, primary_idx_of(ip.nq, shard, off), o, d, k0, k1);
+                } else {
+                    const float4 ra = qa[pos], rb = qb[pos];
+                    o = v3(ra.x, ra.y, ra.z);
+                    d = v3(rb.x, rb.y, rb.z);
+                }
                 ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
                 a = length_squared(d); // hitable.rs:77
                 tbest = RT_FLT_MAX;
@@ -336,26 +368,48 @@ __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float
 struct ShadeParams {
     uint32_t nq, cap;
     int depth, max_depth;
+    uint32_t sort; // 0: process the shard in queue order (depth 0: primary rays are coherent already)
 };
 
 // Shading half of the step: workgroup q owns shard q (reads it, appends survivors to shard q of
 // the output queue through an LDS counter, publishes the new count with a plain store).
+//
+// The 13 material branches and 4 texture kinds diverge badly when a wave holds arbitrary rays
+// (VALU lane utilisation 34 %, profiles/round1).  Rays are therefore processed in super-chunks of
+// RT_SORT_N: a counting sort over the shading class of the hit sphere (DevScene::sph_class; LDS
+// histogram + scan + index permutation, no ray data moves) hands every wave rays of one class,
+// except at class boundaries.  Results do not depend on the processing order.
 // PERLIN_LDS: the Perlin gradient and permutation tables (texture.rs:53-58; 4.75 KB per set) are
 // staged into LDS.
 #define RT_PERLIN_LDS_MAX_SETS 4u
-template <bool PERLIN_LDS>
-__global__ __launch_bounds__(256) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
+#define RT_SORT_N 1024u   // rays per counting sort (4 per thread)
+#define RT_NCLASS 64u
+__host__ __device__ inline size_t shade_lds_bytes(uint32_t n_spheres, uint32_t n_perlin_lds) {
+    size_t b = 16u + RT_NCLASS * 4u * 2u + RT_SORT_N * 2u; // counter, histogram, offsets, permutation
+    b += ((size_t)n_spheres + 15u) & ~(size_t)15u;         // sphere classes
+    b += (size_t)n_perlin_lds * (256u * 16u + 768u);
+    return (b + 15u) & ~(size_t)15u;
+}
+template <bool PERLIN_LDS, bool GEN>
+__global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
                                                const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,
                                                float* __restrict__ rad, ShadeParams tp,
-                                               unsigned long long* __restrict__ stats) {
+                                               unsigned long long* __restrict__ stats,
+                                               const GenParams* __restrict__ gpd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t q = blockIdx.x;
     const uint32_t count = in_counts[q];
     if (count == 0) return; // out_counts[q] stays 0 (cleared per slice)
     uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + 16);
+    uint32_t* s_offs = s_hist + RT_NCLASS;
+    unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_offs + RT_NCLASS);
+    uint8_t* s_class = reinterpret_cast<uint8_t*>(s_perm + RT_SORT_N);
+    const uint32_t class_bytes = (sc.n_spheres + 15u) & ~15u;
+    for (uint32_t i = threadIdx.x; i < sc.n_spheres; i += 256u) s_class[i] = sc.sph_class[i];
     PerlinTables pt{sc.perlin_vec, sc.perlin_perm};
     if (PERLIN_LDS) {
-        float4* lv = reinterpret_cast<float4*>(smem + 16);
+        float4* lv = reinterpret_cast<float4*>(s_class + class_bytes);
         uint8_t* lp = reinterpret_cast<uint8_t*>(lv + sc.n_perlin * 256u);
         for (uint32_t i = threadIdx.x; i < sc.n_perlin * 256u; i += 256u) lv[i] = sc.perlin_vec[i];
         for (uint32_t i = threadIdx.x; i < sc.n_perlin * 768u; i += 256u) lp[i] = sc.perlin_perm[i];
@@ -367,50 +421,98 @@ __global__ __launch_bounds__(256) void k_shade(DevScene sc, Queue qin, const flo
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t n_fetch = 0, n_bad = 0;
     const size_t qbase = (size_t)q * tp.cap;
-    for (uint32_t base = 0; base < count; base += 256u) {
-        const uint32_t i = base + threadIdx.x;
-        bool alive = false;
-        Bounce bo;
-        bo.o = bo.d = bo.attenuation = splat(0.0f);
-        V3 T = splat(0.0f);
-        uint32_t slot = 0, k0 = 0, k1 = 0;
-        if (i < count) {
-            const float4 ra = qin.a[qbase + i], rb = qin.b[qbase + i], rc = qin.c[qbase + i];
-            const float2 h = qh[qbase + i];
-            const V3 o = v3(ra.x, ra.y, ra.z), d = v3(rb.x, rb.y, rb.z);
-            T = v3(rc.x, rc.y, rc.z);
-            slot = __float_as_uint(ra.w), k0 = __float_as_uint(rb.w), k1 = __float_as_uint(rc.w);
-            V3 Lr = splat(0.0f);
-            if (!near_one(d)) { // main.rs:39 assert!: the reference panics; the path is dropped
-                ++n_bad;
-            } else {
-                Rng rng{k0, k1, depth_counter_base(tp.depth)};
-                bo = shade(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch);
-                if (bo.alive) {
-                    alive = tp.depth < tp.max_depth; // survivors of the last depth return 0, main.rs:40-42
-                } else {
-                    Lr = T * bo.radiance; // L = T_n * (emitted | sky)
-                }
-            }
-            if (!alive) {
-                float* r = rad + (size_t)slot * 3u;
-                r[0] = Lr.x, r[1] = Lr.y, r[2] = Lr.z;
+    for (uint32_t base = 0; base < count; base += RT_SORT_N) {
+        const uint32_t n_here = min(RT_SORT_N, count - base);
+        // ---- counting sort of the super-chunk by shading class --------------------------------
+        if (tp.sort) {
+        if (threadIdx.x < RT_NCLASS) s_hist[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t cls[4], rank[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t j = r * 256u + threadIdx.x;
+            cls[r] = 0u, rank[r] = 0u;
+            if (j < n_here) {
+                const int hit = __float_as_int(qh[qbase + base + j].y);
+                cls[r] = hit < 0 ? 0u : (uint32_t)s_class[hit];
+                rank[r] = atomicAdd(&s_hist[cls[r]], 1u);
             }
         }
-        // wave64 compaction: ballot + prefix popcount; the wave claims its slots from the LDS counter
-        const unsigned long long mask = __ballot(alive);
-        if (mask) {
-            uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(s_out, (uint32_t)__popcll(mask));
-            wbase = __builtin_amdgcn_readfirstlane(wbase);
-            if (alive) {
-                const uint32_t rank =
-                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const size_t pos = qbase + wbase + rank;
-                const V3 Tn = T * bo.attenuation;
-                qout.a[pos] = make_float4(bo.o.x, bo.o.y, bo.o.z, __uint_as_float(slot));
-                qout.b[pos] = make_float4(bo.d.x, bo.d.y, bo.d.z, __uint_as_float(k0));
-                qout.c[pos] = make_float4(Tn.x, Tn.y, Tn.z, __uint_as_float(k1));
+        __syncthreads();
+        if (threadIdx.x < 64u) { // exclusive scan of the 64 class counts by wave 0
+            const uint32_t v = s_hist[threadIdx.x];
+            uint32_t incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off);
+                if ((int)lane >= off) incl += t;
+            }
+            s_offs[threadIdx.x] = incl - v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t j = r * 256u + threadIdx.x;
+            if (j < n_here) s_perm[s_offs[cls[r]] + rank[r]] = (unsigned short)j;
+        }
+        __syncthreads();
+        }
+        // ---- shade in class order --------------------------------------------------------------
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t j = r * 256u + threadIdx.x;
+            if (r * 256u >= n_here) break; // block-uniform
+            bool alive = false;
+            Bounce bo;
+            bo.o = bo.d = bo.attenuation = splat(0.0f);
+            V3 T = splat(0.0f);
+            uint32_t slot = 0, k0 = 0, k1 = 0;
+            if (j < n_here) {
+                const uint32_t off = base + (tp.sort ? (uint32_t)s_perm[j] : j);
+                const size_t i = qbase + off;
+                const float2 h = qh[i];
+                V3 o, d;
+                if (GEN) { // depth 0: T = 1, slot = path index, ray regenerated (bitwise the one k_intersect traced)
+                    slot = primary_idx_of(tp.nq, q, off);
+                    gen_primary(*gpd, slot, o, d, k0, k1);
+                    T = splat(1.0f);
+                } else {
+                    const float4 ra = qin.a[i], rb = qin.b[i], rc = qin.c[i];
+                    o = v3(ra.x, ra.y, ra.z), d = v3(rb.x, rb.y, rb.z);
+                    T = v3(rc.x, rc.y, rc.z);
+                    slot = __float_as_uint(ra.w), k0 = __float_as_uint(rb.w), k1 = __float_as_uint(rc.w);
+                }
+                V3 Lr = splat(0.0f);
+                if (!near_one(d)) { // main.rs:39 assert!: the reference panics; the path is dropped
+                    ++n_bad;
+                } else {
+                    Rng rng{k0, k1, depth_counter_base(tp.depth)};
+                    bo = shade(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch);
+                    if (bo.alive) {
+                        alive = tp.depth < tp.max_depth; // survivors of the last depth return 0, main.rs:40-42
+                    } else {
+                        Lr = T * bo.radiance; // L = T_n * (emitted | sky)
+                    }
+                }
+                if (!alive) {
+                    float* rp = rad + (size_t)slot * 3u;
+                    rp[0] = Lr.x, rp[1] = Lr.y, rp[2] = Lr.z;
+                }
+            }
+            // wave64 compaction: ballot + prefix popcount; the wave claims its slots from the LDS counter
+            const unsigned long long mask = __ballot(alive);
+            if (mask) {
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(s_out, (uint32_t)__popcll(mask));
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                if (alive) {
+                    const uint32_t rk =
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    const size_t pos = qbase + wbase + rk;
+                    const V3 Tn = T * bo.attenuation;
+                    qout.a[pos] = make_float4(bo.o.x, bo.o.y, bo.o.z, __uint_as_float(slot));
+                    qout.b[pos] = make_float4(bo.d.x, bo.d.y, bo.d.z, __uint_as_float(k0));
+                    qout.c[pos] = make_float4(Tn.x, Tn.y, Tn.z, __uint_as_float(k1));
+                }
             }
         }
     }
