@@ -287,10 +287,24 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     HostBvh bvh;
     build_sphere_bvh(geo, RT_BVH_MAX_DEPTH, bvh);
     std::vector<uint8_t> sclass(s->n_spheres);
+    std::vector<float4> srec((size_t)s->n_spheres * 4);
+    auto fbits = [](uint32_t u) {
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    };
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         const uint32_t m = s->sph_mat[i], ty = s->mat_type[m];
-        const uint32_t tt = (mat_needs_tex0(ty) && s->mat_tex0[m] < s->n_textures) ? s->tex_type[s->mat_tex0[m]] : 0u;
+        const bool has_t0 = mat_needs_tex0(ty) && s->mat_tex0[m] < s->n_textures;
+        const uint32_t t0 = has_t0 ? s->mat_tex0[m] : 0u;
+        const uint32_t tt = has_t0 ? s->tex_type[t0] : 0u;
         sclass[i] = (uint8_t)(1u + ty * 4u + tt); // < RT_NCLASS
+        // colour slot: the texture's colour 0 for textured materials, the albedo for Metal
+        const float* col = has_t0 ? s->tex_color0 + 3 * (size_t)t0 : s->mat_color + 3 * (size_t)m;
+        srec[4 * (size_t)i + 0] = geo[i];
+        srec[4 * (size_t)i + 1] = make_float4(fbits(ty), fbits(tt), fbits(has_t0 ? s->tex_aux[t0] : 0u), fbits(s->mat_tex1[m]));
+        srec[4 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], s->mat_p0[m]);
+        srec[4 * (size_t)i + 3] = make_float4(s->mat_p1[m], s->mat_p2[m], has_t0 ? s->tex_scale[t0] : 0.0f, fbits(s->mat_tex0[m]));
     }
 
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -305,7 +319,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
         (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
         (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, bvh.a, &ds.bvh_a)) || (rc = upload(ctx, bvh.b, &ds.bvh_b)) ||
-        (rc = upload(ctx, bvh.c, &ds.bvh_c)) || (rc = upload(ctx, bvh.d, &ds.bvh_d)) || (rc = upload(ctx, sclass, &ds.sph_class))) {
+        (rc = upload(ctx, bvh.c, &ds.bvh_c)) || (rc = upload(ctx, bvh.d, &ds.bvh_d)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec))) {
         free_scene(ctx);
         return rc;
     }

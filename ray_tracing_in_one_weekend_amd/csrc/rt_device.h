@@ -202,6 +202,10 @@ struct DevScene {
     // shading class of every sphere (1 + material_type*4 + texture_type of tex0; 0 is "miss"):
     // k_shade sorts the rays of a chunk by class so that a wave runs one material branch
     const uint8_t* sph_class;
+    // Per-sphere shading record, 4 x float4 (one dependent fetch after the hit index instead of
+    // sphere -> material -> texture):  [0] cx cy cz r   [1] type, tex0 type, tex0 aux, tex1 (u32 bits)
+    // [2] colour (ConstantTex / Checker odd / Metal albedo) rgb, p0   [3] p1, p2, tex0 scale, tex0 (u32 bits)
+    const float4* sph_rec;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -277,6 +281,28 @@ __device__ inline V3 texture_value(const DevScene& sc, const PerlinTables& pt, u
     }
     default: // ImageTex
         return image_value(sc, tr.aux, sphere_get_uv(on), n_fetch);
+    }
+}
+
+// Texture::value for the material's first texture, described inline by the sphere record
+// (type, aux, scale, colour 0); only CheckerTex needs its second colour from the TexRec table.
+__device__ inline V3 texture_value_inline(const DevScene& sc, const PerlinTables& pt, uint32_t ttype, uint32_t taux,
+                                          float scale, V3 c0, uint32_t tex, V3 on, V3 p, uint32_t& n_fetch) {
+    switch (ttype) {
+    case 0: // ConstantTex texture.rs:19-23
+        return c0;
+    case 1: { // CheckerTex texture.rs:40-49
+        float sines = sinf(p.x * 10.0f) * sinf(p.y * 10.0f) * sinf(p.z * 10.0f);
+        if (sines < 0.0f) return c0;
+        TexRec tr = sc.texs[tex];
+        return v3(tr.c1r, tr.c1g, tr.c1b);
+    }
+    case 2: { // PerlinTex texture.rs:164-168
+        float s = sinf(10.0f * perlin_turb(pt, taux, p) + scale * p.z);
+        return (s + 1.0f) * 0.5f * splat(1.0f);
+    }
+    default: // ImageTex
+        return image_value(sc, taux, sphere_get_uv(on), n_fetch);
     }
 }
 
@@ -388,15 +414,38 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         out.radiance = sky_value(sc, rd, n_fetch); // main.rs:58
         return out;
     }
-    float4 g = sc.sph_geo[hit];
+    const float4* rec = sc.sph_rec + 4u * (uint32_t)hit;
+    const float4 g = rec[0], r1 = rec[1];
     V3 p = ro + rd * t;                                 // math.rs:64 Ray::at
     V3 on = (p - v3(g.x, g.y, g.z)) / g.w;              // hitable.rs:95 outward_normal
     bool front_face = dot(rd, on) < 0.0f;               // hitable.rs:26
     V3 n = front_face ? on : -on;                       // hitable.rs:27-31
-    MatRec m = sc.mats[sc.sph_mat[hit]];
+    // the material fields are fetched where a branch needs them (keeps the live set small)
+    struct {
+        uint32_t type, tex1;
+        const float4* rec;
+        __device__ __forceinline__ float p0() const { return rec[2].w; }
+        __device__ __forceinline__ float p1() const { return rec[3].x; }
+        __device__ __forceinline__ float p2() const { return rec[3].y; }
+        __device__ __forceinline__ V3 color() const {
+            const float4 c = rec[2];
+            return v3(c.x, c.y, c.z);
+        }
+    } m{__float_as_uint(r1.x), __float_as_uint(r1.w), rec};
+    const uint32_t t0type = __float_as_uint(r1.y), t0aux = __float_as_uint(r1.z);
+    // Every texture-bearing material evaluates its first texture exactly once at (uv(on), p), and
+    // Texture::value draws no random numbers, so it is evaluated here, at ONE call site (the 7-octave
+    // Perlin body is instantiated once and stays inlined; per-branch call sites made the compiler emit
+    // real function calls with a scratch stack).
+    const uint32_t TEX0_USERS = (1u << 0) | (1u << 1) | (1u << 2) | (1u << 5) | (1u << 6) | (1u << 7) | (1u << 8) | (1u << 9) |
+                                (1u << 10) | (1u << 11);
+    V3 tex0_value = splat(0.0f);
+    if ((TEX0_USERS >> m.type) & 1u)
+        tex0_value = texture_value_inline(sc, pt, t0type, t0aux, rec[3].z, m.color(), __float_as_uint(rec[3].w), on, p, n_fetch);
+#define RT_TEX0() tex0_value
     switch (m.type) {
     case 0: // Emission material.rs:21-28
-        out.radiance = texture_value(sc, pt, m.tex0, on, p, n_fetch);
+        out.radiance = RT_TEX0();
         return out;
     case 1: { // Diffuse material.rs:35-46
         V3 sd = n + normalize(random_in_unit_sphere(rng));
@@ -404,20 +453,20 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         if (fabsf(sd.x) < eps && fabsf(sd.y) < eps && fabsf(sd.z) < eps) sd = n; // math.rs:8-11
         out.o = offset_hit_point(p, n);
         out.d = normalize(sd);
-        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch);
+        out.attenuation = RT_TEX0();
         out.alive = true;
         return out;
     }
     case 3: { // Metal material.rs:66-73
-        V3 reflected = reflect(rd, n) + m.p0 * random_in_unit_sphere(rng);
+        V3 reflected = reflect(rd, n) + m.p0() * random_in_unit_sphere(rng);
         out.o = p;
         out.d = normalize(reflected);
-        out.attenuation = v3(m.cr, m.cg, m.cb);
+        out.attenuation = m.color();
         out.alive = dot(reflected, n) > 0.0f;
         return out;
     }
     case 4: { // Dielectric material.rs:79-97
-        float ref_idx = front_face ? 1.0f / m.p0 : m.p0;
+        float ref_idx = front_face ? 1.0f / m.p0() : m.p0();
         float cos_theta = -fminf(dot(rd, n), 1.0f);
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
         bool cannot_refract = sin_theta * ref_idx > 1.0f;
@@ -431,7 +480,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     case 5: { // Isotropic material.rs:103-113
         out.o = p;
         out.d = normalize(random_in_unit_sphere(rng));
-        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch);
+        out.attenuation = RT_TEX0();
         out.alive = true;
         return out;
     }
@@ -449,7 +498,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     float n_dot_o = dot(n, dir_o);
     switch (m.type) {
     case 2: // Lambert material.rs:56
-        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch) * 2.0f * dot(n, dir_o);
+        out.attenuation = RT_TEX0() * 2.0f * dot(n, dir_o);
         break;
     case 6: { // OrenNayar pbr.rs:21-39
         float cos_i = fabsf(dot(n, rd));
@@ -457,7 +506,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         float sin_i = sqrtf(1.0f - cos_i * cos_i);
         float sin_o = sqrtf(1.0f - cos_o * cos_o);
         float max_cos = fmaxf(cos_i * cos_o + sin_i * sin_o, 0.0f);
-        float r2 = m.p0 * m.p0;
+        float r2 = m.p0() * m.p0();
         float a = 1.0f - 0.5f * r2 / (r2 + 0.33f);
         float b = 0.45f * r2 / (r2 + 0.09f);
         float sin_alpha, tan_beta;
@@ -469,7 +518,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
             tan_beta = sin_o / cos_o;
         }
         float w = a + b * max_cos * sin_alpha * tan_beta;
-        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch) * w * 2.0f * cos_o;
+        out.attenuation = RT_TEX0() * w * 2.0f * cos_o;
         break;
     }
     case 7: { // BurleyDiffuse pbr.rs:54-66
@@ -477,9 +526,9 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         float h_dot_o = dot(h, dir_o);
         float fl = schlick_fresnel(n_dot_o);
         float fv = schlick_fresnel(n_dot_i);
-        float fd90 = 0.5f + 2.0f * h_dot_o * h_dot_o * m.p0;
+        float fd90 = 0.5f + 2.0f * h_dot_o * h_dot_o * m.p0();
         float fd = lerpf(1.0f, fd90, fl) * lerpf(1.0f, fd90, fv);
-        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch) * fd * 2.0f * n_dot_o;
+        out.attenuation = RT_TEX0() * fd * 2.0f * n_dot_o;
         break;
     }
     case 8: { // RoughPlastic pbr.rs:164-186
@@ -488,9 +537,9 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         float h_dot_o = dot(h, dir_o);
         float n_dot_h = dot(n, h);
         V3 kd = texture_value(sc, pt, m.tex1, on, p, n_fetch);
-        V3 ks = texture_value(sc, pt, m.tex0, on, p, n_fetch);
-        float roughness = clampf(m.p0, 0.01f, 1.0f);
-        float eta = m.p1;
+        V3 ks = RT_TEX0();
+        float roughness = clampf(m.p0(), 0.01f, 1.0f);
+        float eta = m.p1();
         float f_o = fresnel_dielectric_2(h_dot_o, eta);
         float dd = gtr2(n_dot_h, roughness);
         float gg = smith_masking_gtr2_2(-rd, n, roughness) * smith_masking_gtr2_2(dir_o, n, roughness);
@@ -505,28 +554,28 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         float h_dot_o = dot(h, dir_o);
         float fo = schlick_fresnel(n_dot_o);
         float fi = schlick_fresnel(n_dot_i);
-        float fd90 = 0.5f + 2.0f * h_dot_o * h_dot_o * m.p0;
+        float fd90 = 0.5f + 2.0f * h_dot_o * h_dot_o * m.p0();
         float fd = lerpf(1.0f, fd90, fo) * lerpf(1.0f, fd90, fi);
-        float fss90 = m.p0 * h_dot_o * h_dot_o;
+        float fss90 = m.p0() * h_dot_o * h_dot_o;
         float fss_wi = lerpf(1.0f, fss90, fi);
         float fss_wo = lerpf(1.0f, fss90, fo);
         float fss = 1.25f * (fss_wi * fss_wo * (1.0f / (n_dot_i + n_dot_o) - 0.5f) + 0.5f);
-        out.attenuation = texture_value(sc, pt, m.tex0, on, p, n_fetch) * lerpf(fd, fss, m.p1) * 2.0f * n_dot_o;
+        out.attenuation = RT_TEX0() * lerpf(fd, fss, m.p1()) * 2.0f * n_dot_o;
         break;
     }
     case 10: { // DisneyMetal pbr.rs:236-275
         V3 h = normalize(dir_o - rd);
         float h_dot_o = dot(h, dir_o);
         float n_dot_h = dot(n, h);
-        V3 albedo = texture_value(sc, pt, m.tex0, on, p, n_fetch);
+        V3 albedo = RT_TEX0();
         V3 fm = lerp3(albedo, splat(1.0f), schlick_fresnel(h_dot_o));
         const float alpha_min = 0.0001f;
         float dm, gm;
-        if (m.p1 > -10.0f) {
-            float aspect = sqrtf(1.0f - 0.9f * m.p1);
-            float ax = fmaxf(m.p0 * m.p0 / aspect, alpha_min);
-            float ay = fmaxf(m.p0 * m.p0 * aspect, alpha_min);
-            float rot = m.p2 * 2.0f * RT_PI;
+        if (m.p1() > -10.0f) {
+            float aspect = sqrtf(1.0f - 0.9f * m.p1());
+            float ax = fmaxf(m.p0() * m.p0() / aspect, alpha_min);
+            float ay = fmaxf(m.p0() * m.p0() * aspect, alpha_min);
+            float rot = m.p2() * 2.0f * RT_PI;
             V3 tang = normalize(cross(v3(0.0f, 1.0f, 0.0f), on)); // hitable.rs:96
             V3 h_local = world_to_local_with_rot(n, tang, h, rot);
             dm = gtr2_aniso(h_local, ax, ay);
@@ -534,7 +583,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
             V3 o_local = world_to_local_with_rot(n, tang, dir_o, rot);
             gm = smith_geo_ggx_aniso(i_local, ax, ay) * smith_geo_ggx_aniso(o_local, ax, ay);
         } else {
-            float r2 = fmaxf(m.p0 * m.p0, alpha_min);
+            float r2 = fmaxf(m.p0() * m.p0(), alpha_min);
             dm = gtr2(n_dot_h, r2);
             gm = smith_geo_ggx(n_dot_i, r2) * smith_geo_ggx(n_dot_o, r2);
         }
@@ -545,10 +594,10 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     case 11: { // DisneySheen pbr.rs:290-305
         V3 h = normalize(dir_o - rd);
         float h_dot_o = dot(h, dir_o);
-        V3 albedo = texture_value(sc, pt, m.tex0, on, p, n_fetch);
+        V3 albedo = RT_TEX0();
         float luminance = dot(v3(0.3f, 0.6f, 0.1f), albedo);
         V3 c_tint = luminance > 0.0f ? albedo / luminance : splat(1.0f);
-        V3 c_sheen = lerp3(splat(1.0f), c_tint, m.p0);
+        V3 c_sheen = lerp3(splat(1.0f), c_tint, m.p0());
         V3 f_sheen = c_sheen * schlick_fresnel(h_dot_o);
         out.attenuation = f_sheen * n_dot_o * 2.0f * RT_PI;
         break;
@@ -558,7 +607,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         float h_dot_o = dot(h, dir_o);
         float n_dot_h = dot(n, h);
         float fc = lerpf(0.4f, 1.0f, schlick_fresnel(h_dot_o));
-        float dc = gtr1(n_dot_h, lerpf(0.1f, 0.001f, m.p0));
+        float dc = gtr1(n_dot_h, lerpf(0.1f, 0.001f, m.p0()));
         float gc = smith_geo_ggx(n_dot_i, 0.25f) * smith_geo_ggx(n_dot_o, 0.25f);
         float cc = 0.25f * fc * dc * gc;
         out.attenuation = splat(cc) * n_dot_o * 2.0f * RT_PI;
@@ -568,6 +617,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         out.alive = false;
         break;
     }
+#undef RT_TEX0
     return out;
 }
 

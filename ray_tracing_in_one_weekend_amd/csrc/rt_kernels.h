@@ -182,26 +182,47 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
 // later sphere replaces an earlier one), independent of the visiting order.  Boxes are padded at
 // build time (rt_bvh.h) and entry/exit distances are widened by 2e-6 relative, so a box is never
 // culled when the exact test could accept the sphere inside it.
+//
+// Slab arithmetic: t = b*inv - o*inv as one fused multiply-add per plane (the only place in the
+// library that fuses; it is a culling test, not reference arithmetic).  The rounding of the
+// precomputed o*inv puts an ABSOLUTE error of up to 2^-24*|o*inv| on every plane distance — large
+// when the ray is nearly perpendicular to an axis — so the per-ray slack `eps` = 2.4e-7*max|o*inv|
+// (2x the bound for entry + exit) is added to both limits, next to the 4e-6 relative widening
+// that covers the rounding of inv and of the fma itself.
 template <int BLOCK>
-__device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float a, int& cur,
-                                         int& sp, float& tbest, int& hit) {
+__device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float nox, float noy,
+                                         float noz, float eps, float a, int& cur, int& sp, float& tbest, int& hit) {
     if (cur >= 0) {
         const float4 A = L.nA[cur], B = L.nB[cur], C = L.nC[cur];
         const int4 D = L.nD[cur];
         // left child box: min (A.x, A.y, A.z) max (A.w, B.x, B.y)
+#ifdef RT_SLAB_SUB
         float x0 = (A.x - o.x) * ix, x1 = (A.w - o.x) * ix;
         float y0 = (A.y - o.y) * iy, y1 = (B.x - o.y) * iy;
         float z0 = (A.z - o.z) * iz, z1 = (B.y - o.z) * iz;
+#else
+        float x0 = __builtin_fmaf(A.x, ix, nox), x1 = __builtin_fmaf(A.w, ix, nox);
+        float y0 = __builtin_fmaf(A.y, iy, noy), y1 = __builtin_fmaf(B.x, iy, noy);
+        float z0 = __builtin_fmaf(A.z, iz, noz), z1 = __builtin_fmaf(B.y, iz, noz);
+#endif
         const float tnl = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
         const float tfl = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
         // right child box: min (B.z, B.w, C.x) max (C.y, C.z, C.w)
+#ifdef RT_SLAB_SUB
         x0 = (B.z - o.x) * ix, x1 = (C.y - o.x) * ix;
         y0 = (B.w - o.y) * iy, y1 = (C.z - o.y) * iy;
         z0 = (C.x - o.z) * iz, z1 = (C.w - o.z) * iz;
+#else
+        x0 = __builtin_fmaf(B.z, ix, nox), x1 = __builtin_fmaf(C.y, ix, nox);
+        y0 = __builtin_fmaf(B.w, iy, noy), y1 = __builtin_fmaf(C.z, iy, noy);
+        z0 = __builtin_fmaf(C.x, iz, noz), z1 = __builtin_fmaf(C.w, iz, noz);
+#endif
         const float tnr = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
         const float tfr = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-        const bool hl = tnl * 0.999998f <= fminf(tfl * 1.000002f, tbest) && D.x != (int)0x80000000;
-        const bool hr = tnr * 0.999998f <= fminf(tfr * 1.000002f, tbest) && D.y != (int)0x80000000;
+        // entry <= exit and entry <= closest so far, both widened (tn >= 0, so widening the right side is enough)
+        const float tb = __builtin_fmaf(tbest, 1.000004f, eps);
+        const bool hl = tnl <= fminf(__builtin_fmaf(tfl, 1.000004f, eps), tb) && D.x != (int)0x80000000;
+        const bool hr = tnr <= fminf(__builtin_fmaf(tfr, 1.000004f, eps), tb) && D.y != (int)0x80000000;
         if (hl && hr) {
             const bool left_first = tnl <= tnr;
             L.stack[sp * BLOCK] = (unsigned short)(left_first ? D.y : D.x);
@@ -271,7 +292,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
     bool exhausted = false; // wave-uniform: the workgroup has no unclaimed rays left
     bool has = false;
     V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
-    float ix = 0.f, iy = 0.f, iz = 0.f, a = 1.0f, tbest = RT_FLT_MAX;
+    float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, eps = 0.f, a = 1.0f, tbest = RT_FLT_MAX;
     int hit = -1, cur = 0, sp = 0;
     size_t pos = 0;
     for (;;) {
@@ -302,6 +323,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
                     d = v3(rb.x, rb.y, rb.z);
                 }
                 ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+                nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
+                eps = 2.4e-7f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
                 a = length_squared(d); // hitable.rs:77
                 tbest = RT_FLT_MAX;
                 hit = -1;
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
             if (exhausted) break;
             continue;
         }
-        if (has && bvh_step<BLOCK>(L, o, d, ix, iy, iz, a, cur, sp, tbest, hit)) {
+        if (has && bvh_step<BLOCK>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, cur, sp, tbest, hit)) {
             qh[pos] = make_float2(tbest, __int_as_float(hit));
             has = false;
         }
@@ -390,8 +413,11 @@ __host__ __device__ inline size_t shade_lds_bytes(uint32_t n_spheres, uint32_t n
     b += (size_t)n_perlin_lds * (256u * 16u + 768u);
     return (b + 15u) & ~(size_t)15u;
 }
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
 template <bool PERLIN_LDS, bool GEN>
-__global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
+__global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
                                                const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,
                                                float* __restrict__ rad, ShadeParams tp,
                                                unsigned long long* __restrict__ stats,
@@ -604,8 +630,10 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
         __syncthreads();
         if (active && sc.n_spheres) {
             const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+            const float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
+            const float eps = 2.4e-7f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
             int cur = 0, sp = 0;
-            while (!bvh_step<BLOCK>(L, o, d, ix, iy, iz, a, cur, sp, tbest, hit)) {
+            while (!bvh_step<BLOCK>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, cur, sp, tbest, hit)) {
             }
         }
     } else {
