@@ -29,6 +29,26 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
+def pmc_traffic(workload_key):
+    """HBM bytes per trace-step launch from the committed PMC pass of this same command
+    (scripts/collect_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections).
+    bench.py cannot profile itself, so the number comes from profiles/; null when absent or stale."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "traffic*.json"))):
+        try:
+            t = json.load(open(p))
+        except (OSError, ValueError):
+            continue
+        cfg = t.get("bench_config") or {}
+        if cfg.get("workload") == workload_key:
+            best = (p, t)
+    if not best:
+        return None, None
+    p, t = best
+    return t["trace_step_bytes_per_launch"], os.path.relpath(p, ROOT)
+
+
 def usable_cores():
     """Host cores this process may actually use: the cgroup CPU quota (cpu.max) caps the GPU box's
     share well below os.cpu_count(), and oversubscribing the quota only adds throttling."""
@@ -155,6 +175,11 @@ def main():
         trace_bytes = sum(s.bytes_trace_algorithmic for s in stats)
         launches = sum(s.n_trace_launches for s in stats)
         achieved = trace_bytes / max(trace_s, 1e-12) / 1e9
+        workload = (f"demo_scene.rs sphere_scene (random-spheres, 533 spheres) {nx}x{ny}, "
+                    f"{args.spp} spp per GPU ({spp_total} spp total), max_depth {args.max_depth}, "
+                    f"seed 95, counter RNG; rows sharded in bands of {args.band} over {world} GPU(s)"
+                    + (", RCCL all_gather of the f32 framebuffer per step" if world > 1 else ""))
+        traffic, traffic_src = pmc_traffic(workload)
         out = {
             "metric": "Mray/s (primary+secondary) at 1920x1080/256spp",
             "value": round(rays_total / elapsed_max / 1e6, 3),
@@ -168,22 +193,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"demo_scene.rs sphere_scene (random-spheres, 533 spheres) {nx}x{ny}, "
-                                   f"{args.spp} spp per GPU ({spp_total} spp total), max_depth {args.max_depth}, "
-                                   f"seed 95, counter RNG; rows sharded in bands of {args.band} over {world} GPU(s)"
-                                   + (", RCCL all_gather of the f32 framebuffer per step" if world > 1 else ""),
+            "config": {"workload": workload,
                        "paths_per_step": int(s0.n_paths) * world, "rays_per_step_rank0": int(s0.n_rays),
                        "rays_per_path": round(s0.n_rays / max(s0.n_paths, 1), 4),
                        "spp_slices": int(s0.n_slices)},
-            "roofline": {"kernel": "k_trace_shade", "bound": "hbm", "achieved": round(achieved, 2),
+            "roofline": {"kernel": "trace step = k_intersect + k_shade (the survey's k_trace_shade, split)", "bound": "hbm",
+                         "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": round(trace_bytes / max(launches, 1), 1),
                          "avg_launch_us": round(trace_s / max(launches, 1) * 1e6, 3),
                          "launches": launches,
-                         "note": "algorithmic bytes = 48 B/ray read + 48 B/surviving ray written + 12 B/path radiance "
-                                 "(SURVEY.md 8(d): 96 B/ray + 24 B/path over gen+trace+resolve); time = HIP events "
-                                 "around the trace launches of every slice on the launch stream"},
+                         "note": "per launch = per kernel launch of the step (2 per depth); algorithmic bytes = 48 B/ray read + "
+                                 "48 B/surviving ray written + 12 B/path radiance (SURVEY.md 8(d): 96 B/ray + 24 B/path over "
+                                 "gen+trace+resolve); time = HIP events around the trace launches of every slice on the launch "
+                                 "stream; traffic = PMC FETCH_SIZE*2 + WRITE_SIZE of both kernels per launch"},
             "whole_path": {"bytes_algorithmic_per_step": int(s0.bytes_algorithmic),
                            "device_seconds_per_step": round(s0.seconds_device, 6),
                            "hbm_frac": round(s0.bytes_algorithmic / max(s0.seconds_device, 1e-12) / 1e9 / HBM_PEAK_GBPS, 5)},

@@ -278,3 +278,63 @@ def test_error_behaviour(rt):
     with pytest.raises(rt.RtError, match="material index"):
         r.upload(fs)
     r.close()
+
+
+def test_config4_and_5_full_resolution_low_spp(rt, orc, renderer):
+    """BASELINE.json configs 4 (earthmap + newport_loft env sky) and 5 (pbr.rs sweep) at their full
+    1920x1080 resolution and 2 spp against the oracle: exact ray and texel-fetch counts, RMSE in tolerance."""
+    for name, depth, tol in (("earth_env_scene", 50, RMSE_TOL), ("pbr_sweep_scene", 50, 2e-3)):
+        scene = rt.Scene.build(name, 16 / 9)
+        renderer.upload(scene)
+        p = rt.make_params(1920, 1080, 2, max_depth=depth)
+        img, _, st = renderer.render(scene.camera, p)
+        ref, _, so = _oracle(orc, scene, p)
+        assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth), name
+        assert st.n_texture_fetches == so.n_texture_fetches, name
+        fin = np.isfinite(ref) & np.isfinite(img)
+        assert fin.mean() > 0.9999
+        assert rmse_display(np.where(fin, img, 0), np.where(fin, ref, 0)) <= tol, name
+
+
+def test_config3_resolution_sharded_8_ways(rt, renderer):
+    """BASELINE.json config 3 geometry: 3840x2160 split over 8 row-interleaved shards (rendered one after
+    the other on this GPU) reassembles to the unsharded frame bit for bit; 1 spp keeps it short."""
+    from ray_tracing_in_one_weekend_amd import shard
+    scene = rt.Scene.build("sphere_scene", 16 / 9)
+    renderer.upload(scene)
+    nx, ny = 3840, 2160
+    full, _, st = renderer.render(scene.camera, rt.make_params(nx, ny, 1, max_depth=50))
+    parts, rays = [], 0
+    for r in range(8):
+        im, _, s = renderer.render(scene.camera, rt.make_params(nx, ny, 1, max_depth=50, shard_band=8, shard_count=8, shard_id=r))
+        parts.append(im)
+        rays += s.n_rays
+    out = shard.deinterleave(parts, ny, 8, 8)
+    assert np.array_equal(out.view(np.uint32), full.view(np.uint32)) and rays == st.n_rays
+    assert st.n_paths == nx * ny
+
+
+def test_scene_too_large_for_the_lds_bvh_uses_the_list_walk(rt, orc, renderer):
+    """3000 spheres: the BVH (2999 nodes x 64 B) no longer fits LDS, so closest hit falls back to the
+    tiled list walk (two LDS tiles); results still equal the oracle's."""
+    rng = np.random.default_rng(11)
+    s = rt.Scene.new()
+    mats = [s.material(rt._ffi.MAT_DIFFUSE, tex0=s.constant_tex(rng.uniform(0.2, 0.9, 3))) for _ in range(8)]
+    mats.append(s.material(rt._ffi.MAT_METAL, color=(0.8, 0.8, 0.9), p=(0.1,)))
+    mats.append(s.material(rt._ffi.MAT_DIELECTRIC, p=(1.5,)))
+    s.sphere((0, -1000, 0), 1000.0, mats[0], "ground")
+    for i in range(2999):
+        c = rng.uniform(-20, 20, 3)
+        c[1] = rng.uniform(0.1, 3.0)
+        s.sphere(c, float(rng.uniform(0.05, 0.3)), mats[int(rng.integers(0, len(mats)))], f"s{i}")
+    s.set_camera((13, 4, 3), (0, 0.5, 0), (0, 1, 0), 40, 16 / 9)
+    s.finish()
+    renderer.upload(s)
+    p = rt.make_params(160, 90, 2, max_depth=10)
+    img, _, st = renderer.render(s.camera, p)
+    ref, _, so = _oracle(orc, s, p)
+    assert st.n_rays == so.n_rays and rmse_display(img, ref) <= RMSE_TOL
+    o, d, keys = rays_on_scene(4000, 21)
+    g = renderer.debug_bounce(o, d, keys)
+    c = orc.debug_bounce(s.flat_ptr, o, d, keys, accel=orc.ACCEL_LIST)
+    assert np.array_equal(g["hit"], c["hit"]) and np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
