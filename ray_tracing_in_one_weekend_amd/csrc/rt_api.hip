@@ -307,27 +307,32 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         srec[4 * (size_t)i + 3] = make_float4(s->mat_p1[m], s->mat_p2[m], has_t0 ? s->tex_scale[t0] : 0.0f, fbits(s->mat_tex0[m]));
     }
 
+    HostBvh4 bvh4;
+    collapse_bvh4(bvh, bvh4);
+
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
     DevScene ds{};
-    ds.n_bvh_nodes = (uint32_t)bvh.a.size();
-    ds.bvh_depth = bvh.depth;
+    ds.n_bvh4_nodes = (uint32_t)bvh4.id.size();
+    ds.bvh4_depth = bvh4.depth;
     ds.n_spheres = s->n_spheres, ds.n_materials = s->n_materials, ds.n_textures = s->n_textures;
     ds.n_perlin = s->n_perlin, ds.n_images = s->n_images, ds.sky_type = s->sky_type, ds.sky_image = s->sky_image;
     int rc;
     if ((rc = upload(ctx, geo, &ds.sph_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
         (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
-        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, bvh.a, &ds.bvh_a)) || (rc = upload(ctx, bvh.b, &ds.bvh_b)) ||
-        (rc = upload(ctx, bvh.c, &ds.bvh_c)) || (rc = upload(ctx, bvh.d, &ds.bvh_d)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec))) {
+        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
+        (rc = upload(ctx, bvh4.p[0], &ds.bvh4_p[0])) || (rc = upload(ctx, bvh4.p[1], &ds.bvh4_p[1])) ||
+        (rc = upload(ctx, bvh4.p[2], &ds.bvh4_p[2])) || (rc = upload(ctx, bvh4.p[3], &ds.bvh4_p[3])) ||
+        (rc = upload(ctx, bvh4.p[4], &ds.bvh4_p[4])) || (rc = upload(ctx, bvh4.p[5], &ds.bvh4_p[5]))) {
         free_scene(ctx);
         return rc;
     }
     ctx->ds = ds;
     ctx->has_scene = true;
-    // k_intersect keeps nodes + spheres + one u16 stack column per lane (bvh.depth levels) in LDS
-    ctx->isect_lds = bvh_lds_bytes(ds.n_bvh_nodes, ds.n_spheres, RT_BVH_BLOCK, bvh.depth);
-    ctx->use_bvh = ds.n_spheres > 0 && ds.n_bvh_nodes > 0 && ds.n_bvh_nodes < 32768 && ds.n_spheres <= 32768 &&
+    // k_intersect keeps nodes + spheres + one u16 stack column per lane in LDS
+    ctx->isect_lds = bvh_lds_bytes(ds, RT_BVH_BLOCK);
+    ctx->use_bvh = ds.n_spheres > 0 && ds.n_bvh4_nodes > 0 && ds.n_bvh4_nodes < 32768 && ds.n_spheres <= 32768 &&
                    bvh.depth <= RT_BVH_MAX_DEPTH && ctx->isect_lds <= ctx->lds_limit;
     if (ctx->use_bvh) {
         RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false>),

@@ -25,6 +25,14 @@ struct HostBvh {
     uint32_t depth = 0;
 };
 
+// 4-wide collapse of a HostBvh: node = min_x[4], min_y[4], min_z[4], max_x[4], max_y[4], max_z[4]
+// (one float4 per plane over the 4 children) + child ids (>= 0 inner, < 0 sphere ~id, INT_MIN empty).
+struct HostBvh4 {
+    std::vector<float4> p[6];
+    std::vector<int4> id;
+    uint32_t depth = 0;
+};
+
 namespace bvh_detail {
 
 struct Box {
@@ -175,6 +183,63 @@ inline void build_sphere_bvh(const std::vector<float4>& geo, uint32_t max_depth,
         b.build(0, geo.size(), 0);
         if (out.depth <= max_depth) return;
     }
+}
+
+namespace bvh_detail {
+inline int collapse4(const HostBvh& b, int n, HostBvh4& o, uint32_t depth) {
+    o.depth = std::max(o.depth, depth + 1);
+    const int me = (int)o.id.size();
+    for (auto& v : o.p) v.push_back(float4{});
+    o.id.push_back(int4{});
+    float mn[3][4], mx[3][4];
+    int cid[4];
+    int cnt = 0;
+    auto add = [&](const float* bmn, const float* bmx, int child) {
+        for (int k = 0; k < 3; ++k) mn[k][cnt] = bmn[k], mx[k][cnt] = bmx[k];
+        cid[cnt++] = child;
+    };
+    auto boxes = [&](int node, float lmn[3], float lmx[3], float rmn[3], float rmx[3]) {
+        const float4 A = b.a[(size_t)node], B = b.b[(size_t)node], C = b.c[(size_t)node];
+        lmn[0] = A.x, lmn[1] = A.y, lmn[2] = A.z, lmx[0] = A.w, lmx[1] = B.x, lmx[2] = B.y;
+        rmn[0] = B.z, rmn[1] = B.w, rmn[2] = C.x, rmx[0] = C.y, rmx[1] = C.z, rmx[2] = C.w;
+    };
+    float lmn[3], lmx[3], rmn[3], rmx[3];
+    boxes(n, lmn, lmx, rmn, rmx);
+    const int ch[2] = {b.d[(size_t)n].x, b.d[(size_t)n].y};
+    const float* cmn[2] = {lmn, rmn};
+    const float* cmx[2] = {lmx, rmx};
+    // inner grandchildren are marked with (1 << 30) + node and resolved after this node is filled
+    for (int k = 0; k < 2; ++k) {
+        if (ch[k] == INT_MIN) continue;
+        if (ch[k] >= 0) {
+            float gl[3], glx[3], gr[3], grx[3];
+            boxes(ch[k], gl, glx, gr, grx);
+            const int g[2] = {b.d[(size_t)ch[k]].x, b.d[(size_t)ch[k]].y};
+            if (g[0] != INT_MIN) add(gl, glx, g[0] >= 0 ? (1 << 30) + g[0] : g[0]);
+            if (g[1] != INT_MIN) add(gr, grx, g[1] >= 0 ? (1 << 30) + g[1] : g[1]);
+        } else {
+            add(cmn[k], cmx[k], ch[k]);
+        }
+    }
+    for (int k = 0; k < cnt; ++k)
+        if (cid[k] >= (1 << 30)) cid[k] = collapse4(b, cid[k] - (1 << 30), o, depth + 1);
+    for (int k = cnt; k < 4; ++k) {
+        for (int ax = 0; ax < 3; ++ax) mn[ax][k] = FLT_MAX, mx[ax][k] = -FLT_MAX;
+        cid[k] = INT_MIN;
+    }
+    for (int ax = 0; ax < 3; ++ax) {
+        o.p[ax][(size_t)me] = make_float4(mn[ax][0], mn[ax][1], mn[ax][2], mn[ax][3]);
+        o.p[3 + ax][(size_t)me] = make_float4(mx[ax][0], mx[ax][1], mx[ax][2], mx[ax][3]);
+    }
+    o.id[(size_t)me] = make_int4(cid[0], cid[1], cid[2], cid[3]);
+    return me;
+}
+} // namespace bvh_detail
+
+inline void collapse_bvh4(const HostBvh& b, HostBvh4& out) {
+    out = HostBvh4();
+    if (b.a.empty()) return;
+    bvh_detail::collapse4(b, 0, out, 0);
 }
 
 } // namespace rt

@@ -190,15 +190,13 @@ struct DevScene {
     const uint8_t* perlin_perm; // [n_perlin*3*256]
     const ImgRec* imgs;
     const float4* texels;       // rgb_
-    // LDS-resident BVH2 over the spheres, built at upload (rt_bvh.h); children boxes live in
-    // the parent: A = (lmin.xyz, lmax.x) B = (lmax.yz, rmin.xy) C = (rmin.z, rmax.xyz),
-    // D = (left, right, 0, 0); child >= 0: inner node, child < 0: sphere ~child, INT_MIN: empty
-    uint32_t n_bvh_nodes;
-    uint32_t bvh_depth;
-    const float4* bvh_a;
-    const float4* bvh_b;
-    const float4* bvh_c;
-    const int4* bvh_d;
+    // LDS-resident 4-wide BVH over the spheres, built at upload (rt_bvh.h HostBvh4): per node one
+    // float4 per box plane over the 4 children (min_x, min_y, min_z, max_x, max_y, max_z) + child ids:
+    // id >= 0: inner node, id < 0: sphere ~id, INT_MIN: empty slot
+    uint32_t n_bvh4_nodes;
+    uint32_t bvh4_depth;
+    const float4* bvh4_p[6];
+    const int4* bvh4_id;
     // shading class of every sphere (1 + material_type*4 + texture_type of tex0; 0 is "miss"):
     // k_shade sorts the rays of a chunk by class so that a wave runs one material branch
     const uint8_t* sph_class;
