@@ -109,9 +109,16 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # RTOW_DIST_BACKEND=gloo: rehearsal of the multi-process path on a box with fewer GPUs than ranks
+    # (ranks share devices, the gather goes through host memory); the real run is nccl == RCCL over xGMI
+    backend = os.environ.get("RTOW_DIST_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     import ray_tracing_in_one_weekend_amd as rt
     from ray_tracing_in_one_weekend_amd import shard
@@ -119,7 +126,7 @@ def main():
     rt.register_default_images()
     nx, ny = args.nx, args.ny
     scene = rt.Scene.build("sphere_scene", nx / ny)
-    renderer = rt.Renderer(local_rank)  # raises if librtow_mi355x.so is missing
+    renderer = rt.Renderer(device_index)  # raises if librtow_mi355x.so is missing
     renderer.upload(scene)
     spp_total = args.spp * world
     params = rt.make_params(nx, ny, spp_total, max_depth=args.max_depth, seed=95, shard_band=args.band,
@@ -134,8 +141,11 @@ def main():
 
     def step(want_stats):
         st = renderer.render_device(scene.camera, params, local.data_ptr(), stream=stream, want_stats=want_stats)
-        if world > 1:
+        if world > 1 and backend == "nccl":
             full = shard.gather_framebuffer(local, ny, args.band)  # RCCL all_gather + de-interleave
+        elif world > 1:
+            torch.cuda.current_stream().synchronize()
+            full = shard.gather_framebuffer(local.cpu(), ny, args.band)
         else:
             full = local
         return st, full
@@ -145,6 +155,14 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce_(t, op):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        return c
 
     for _ in range(args.warmup):
         step(False)
@@ -161,10 +179,8 @@ def main():
     t = torch.tensor([elapsed, float(rays_local), sum(s.seconds_trace for s in stats),
                       float(sum(s.bytes_trace_algorithmic for s in stats))], dtype=torch.float64, device="cuda")
     if world > 1:
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        tmax = reduce_(t.clone(), dist.ReduceOp.MAX)
+        tsum = reduce_(t.clone(), dist.ReduceOp.SUM)
         elapsed_max, rays_total = tmax[0].item(), tsum[1].item()
     else:
         elapsed_max, rays_total = elapsed, float(rays_local)
