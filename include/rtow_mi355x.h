@@ -162,6 +162,11 @@ typedef struct RtParams {
 /* Closest hit by the plain list walk (HitableList::hit order, hitable.rs:117-132) instead of the
  * LDS-resident BVH.  Results are identical either way; the flag exists for cross-checking. */
 #define RT_FLAG_BRUTE_FORCE 1u
+/* Russian roulette, the estimator the reference keeps commented out at main.rs:49-53: after a
+ * successful scatter draw one more f32; the path continues with probability
+ * threshold = attenuation.max_element() and its attenuation is divided by the threshold.
+ * Unbiased, NOT the reference's default estimator (opt-in; paths get ~2x shorter at depth 50). */
+#define RT_FLAG_RUSSIAN_ROULETTE 2u
 /* Record HIP events around the kernels of every depth of the FIRST slice; read them back with
  * rt_get_depth_timings().  Diagnostic only (adds two event records per depth). */
 #define RT_FLAG_TIME_DEPTHS 4u

@@ -690,6 +690,7 @@ struct Ctx {
     const RtFlatScene* fs;
     const Bvh* bvh;   /* nullptr => HitableList linear walk */
     int max_depth;
+    bool russian_roulette = false; /* main.rs:49-53, commented out in the reference (RT_FLAG_RUSSIAN_ROULETTE) */
     uint64_t n_rays = 0;
     uint64_t n_tex = 0;
     uint64_t n_bad = 0;
@@ -924,7 +925,13 @@ V3 ray_color(Ctx& cx, Rng& rng, const Ray& r, int depth) {
         V3 attenuation = splat(1.0f);
         V3 ret = mat_emitted(cx, rec.mat, rec.uv, rec.p);
         if (mat_scatter(cx, rng, rec.mat, r, rec, attenuation, scattered)) {
-            ret = ret + attenuation * ray_color(cx, rng, scattered, depth + 1);
+            if (cx.russian_roulette) { /* main.rs:49-53 */
+                float russian_roulette = rng.next_f32();
+                float threshold = std::fmax(attenuation.x, std::fmax(attenuation.y, attenuation.z)); /* max_element */
+                if (russian_roulette < threshold) ret = ret + attenuation * ray_color(cx, rng, scattered, depth + 1) / threshold;
+            } else {
+                ret = ret + attenuation * ray_color(cx, rng, scattered, depth + 1);
+            }
         }
         return ret;
     }
@@ -956,7 +963,13 @@ V3 ray_color_iterative(Ctx& cx, Rng& rng, Ray r) {
             if (emissive) return T * mat_emitted(cx, rec.mat, rec.uv, rec.p);
             return splat(0.0f);
         }
-        T = depth == 0 ? attenuation : T * attenuation;
+        T = T * attenuation;
+        if (cx.russian_roulette) {
+            float rr = rng.next_f32();
+            float threshold = std::fmax(attenuation.x, std::fmax(attenuation.y, attenuation.z));
+            if (!(rr < threshold)) return splat(0.0f);
+            T = T / threshold;
+        }
         r = scattered;
     }
 }
@@ -1052,6 +1065,7 @@ int orc_render(const RtFlatScene* fs, const RtCamera* cam, const RtParams* prm, 
         cx.fs = fs;
         cx.bvh = (opt->accel == 1 && bvh.root >= 0) ? &bvh : nullptr;
         cx.max_depth = prm->max_depth;
+        cx.russian_roulette = (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) != 0;
         std::vector<Ray> rays(spp);
         for (;;) {
             uint32_t i = next_col.fetch_add(1); /* one job per column, main.rs:77 */

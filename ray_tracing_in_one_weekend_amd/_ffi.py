@@ -14,6 +14,7 @@ HOST_LIB_PATH = os.path.join(_PKG_DIR, "librtow_host.so")
 
 RT_NO_TEX = 0xFFFFFFFF
 FLAG_BRUTE_FORCE = 1
+FLAG_RUSSIAN_ROULETTE = 2
 FLAG_TIME_DEPTHS = 4
 RTH_INVALID = 0xFFFFFFFF
 

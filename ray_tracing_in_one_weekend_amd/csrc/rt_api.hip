@@ -486,7 +486,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
                 hipLaunchKernelGGL(k_intersect_list, dim3(nq), dim3(256), list_lds, st, ctx->ds, qi.a, qi.b, qhit, cin, ip);
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth + 1], st));
             // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
-            const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u};
+            const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u,
+                                 (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u};
 #define RT_LAUNCH_SHADE(P, G) \
     hipLaunchKernelGGL((k_shade<P, G>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals, gpd)
             if (perlin_lds && gen) RT_LAUNCH_SHADE(true, true);

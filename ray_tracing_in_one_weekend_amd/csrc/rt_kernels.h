@@ -385,6 +385,7 @@ struct ShadeParams {
     uint32_t nq, cap;
     int depth, max_depth;
     uint32_t sort; // 0: process the shard in queue order (depth 0: primary rays are coherent already)
+    uint32_t russian_roulette; // main.rs:49-53 (commented out in the reference), RT_FLAG_RUSSIAN_ROULETTE
 };
 
 // Shading half of the step: workgroup q owns shard q (reads it, appends survivors to shard q of
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
             Bounce bo;
             bo.o = bo.d = bo.attenuation = splat(0.0f);
             V3 T = splat(0.0f);
+            float rr_threshold = 0.0f;
             uint32_t slot = 0, k0 = 0, k1 = 0;
             if (j < n_here) {
                 const uint32_t off = base + (tp.sort ? (uint32_t)s_perm[j] : j);
@@ -506,6 +508,11 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
                 } else {
                     Rng rng{k0, k1, depth_counter_base(tp.depth)};
                     bo = shade(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch);
+                    if (bo.alive && tp.russian_roulette) { // main.rs:49-53
+                        const float rr = rng.next();
+                        rr_threshold = fmaxf(bo.attenuation.x, fmaxf(bo.attenuation.y, bo.attenuation.z)); // max_element
+                        if (!(rr < rr_threshold)) bo.alive = false; // the path ends without a further contribution
+                    }
                     if (bo.alive) {
                         alive = tp.depth < tp.max_depth; // survivors of the last depth return 0, main.rs:40-42
                     } else {
@@ -527,7 +534,8 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
                     const uint32_t rk =
                         __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                     const size_t pos = qbase + wbase + rk;
-                    const V3 Tn = T * bo.attenuation;
+                    V3 Tn = T * bo.attenuation;
+                    if (tp.russian_roulette) Tn = Tn / rr_threshold; // (T * a) / threshold
                     qout.a[pos] = make_float4(bo.o.x, bo.o.y, bo.o.z, __uint_as_float(slot));
                     qout.b[pos] = make_float4(bo.d.x, bo.d.y, bo.d.z, __uint_as_float(k0));
                     qout.c[pos] = make_float4(Tn.x, Tn.y, Tn.z, __uint_as_float(k1));

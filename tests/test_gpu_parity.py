@@ -338,3 +338,20 @@ def test_scene_too_large_for_the_lds_bvh_uses_the_list_walk(rt, orc, renderer):
     g = renderer.debug_bounce(o, d, keys)
     c = orc.debug_bounce(s.flat_ptr, o, d, keys, accel=orc.ACCEL_LIST)
     assert np.array_equal(g["hit"], c["hit"]) and np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
+
+
+def test_russian_roulette_opt_in(rt, orc, renderer):
+    """RT_FLAG_RUSSIAN_ROULETTE = the estimator commented out at main.rs:49-53; GPU == oracle with the flag
+    (exact ray counts), and the estimate stays unbiased with far fewer rays."""
+    scene = rt.Scene.build("sphere_scene", 16 / 9)
+    renderer.upload(scene)
+    p = rt.make_params(320, 180, 16, max_depth=50, flags=rt._ffi.FLAG_RUSSIAN_ROULETTE)
+    img, _, st = renderer.render(scene.camera, p)
+    ref, _, so = _oracle(orc, scene, p)
+    it, _, si = _oracle(orc, scene, p, estimator=orc.EST_ITERATIVE)
+    assert st.n_rays == so.n_rays == si.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
+    assert rmse_display(img, it) <= 2e-5 and rmse_display(img, ref) <= RMSE_TOL
+    plain, _, sp = renderer.render(scene.camera, rt.make_params(320, 180, 16, max_depth=50))
+    assert st.n_rays < 0.9 * sp.n_rays
+    # unbiased: compare LINEAR means (the gamma/clamp of the display transform is not linear in the noise)
+    assert abs(img.mean() - plain.mean()) / plain.mean() < 0.01

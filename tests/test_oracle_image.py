@@ -121,3 +121,16 @@ def test_stats_formulae(rt, orc, cfg1):
     assert st.n_paths == p.nx * p.ny * p.spp and st.rays_per_depth[0] == st.n_paths
     assert st.n_rays == sum(st.rays_per_depth) and st.rays_per_depth[p.max_depth + 1] == 0
     assert st.bytes_algorithmic == 96 * st.n_rays + 24 * st.n_paths + 12 * st.n_texture_fetches
+
+
+def test_russian_roulette_is_unbiased_and_shortens_paths(rt, orc, cfg1):
+    scene, _ = cfg1
+    p0 = rt.make_params(200, 112, 32, max_depth=50)
+    p1 = rt.make_params(200, 112, 32, max_depth=50, flags=rt._ffi.FLAG_RUSSIAN_ROULETTE)
+    a, _, sa = orc.render(scene.flat_ptr, scene.camera, p0, orc.options())
+    b, _, sb = orc.render(scene.flat_ptr, scene.camera, p1, orc.options())
+    assert sb.n_rays < sa.n_rays and sum(sb.rays_per_depth[20:]) < sum(sa.rays_per_depth[20:])
+    assert abs(a.mean() - b.mean()) / a.mean() < 0.01  # linear means: the estimator is unbiased
+    # the two estimator orders agree with the flag as well
+    c, _, sc = orc.render(scene.flat_ptr, scene.camera, p1, orc.options(estimator=orc.EST_ITERATIVE))
+    assert sc.n_rays == sb.n_rays and rmse_display(b, c) < 1e-6
