@@ -38,8 +38,8 @@ int rth_register_image(const char* path, uint32_t w, uint32_t h, const float* rg
 /* Re-seeds the thread-local RNG (lib.rs:8; default 1995) that PerlinTex::new draws from. */
 void rth_rng_reseed(uint64_t seed);
 
-/* Runs a named scene function: "sphere_scene", "test_sphere", "earth_env_scene",
- * "pbr_sweep_scene"; flattens world + sky + camera.  The thread RNG is reset to its
+/* Runs a named scene function: "sphere_scene", "test_sphere", "simple_light_scene",
+ * "earth_env_scene", "pbr_sweep_scene"; flattens world + sky + camera.  The thread RNG is reset to its
  * fresh-process state (seed 1995) first, so repeated builds give identical Perlin tables. */
 int rth_scene_build(const char* name, float aspect_ratio, RthScene** out);
 
@@ -53,6 +53,9 @@ uint32_t rth_tex_image(RthScene* s, const char* path);
  * p = the scalar fields in the order documented at RtMatType. */
 uint32_t rth_material(RthScene* s, uint32_t type, uint32_t tex0, uint32_t tex1, const float color[3], const float p[4]);
 uint32_t rth_sphere(RthScene* s, const float c[3], float r, uint32_t material, const char* name);
+/* hitable.rs:244-362 XYRect/XZRect/YZRect { min, max, mat } (axis = RtRectAxis) and hitable.rs:364-383 GBox::new */
+uint32_t rth_rect(RthScene* s, uint32_t axis, const float mn[3], const float mx[3], uint32_t material);
+uint32_t rth_gbox(RthScene* s, const float mn[3], const float mx[3], uint32_t material);
 /* sky = RtSkyType; env_path only for RT_SKY_ENV */
 int rth_set_sky(RthScene* s, uint32_t sky, const char* env_path);
 int rth_set_camera(RthScene* s, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1u
+#define RT_ABI_VERSION 2u
 
 /* error codes */
 #define RT_OK 0
@@ -76,13 +76,22 @@ enum RtSkyType {
     RT_SKY_ENV = 2       /* tex_sky_color  demo_scene.rs:22-26, image = sky_image */
 };
 
+/* Axis-aligned rectangle kinds (hitable.rs:244-362): the axis that is constant on the rectangle.
+ * The plane coordinate is min[axis] (the reference reads `self.min.z` etc. and ignores max[axis]). */
+enum RtRectAxis {
+    RT_RECT_YZ = 0, /* YZRect hitable.rs:324-362  x = min.x, normal +X, uv = (y, z) */
+    RT_RECT_XZ = 1, /* XZRect hitable.rs:284-322  y = min.y, normal +Y, uv = (x, z) */
+    RT_RECT_XY = 2  /* XYRect hitable.rs:244-282  z = min.z, normal +Z, uv = (x, y) */
+};
+
 #define RT_NO_TEX 0xFFFFFFFFu
 #define RT_PERLIN_POINTS 256u /* texture.rs:51 */
 
 /*
  * Flattened structure-of-arrays scene.  Replaces `Vec<Arc<dyn Hitable>>` + the trait
- * objects behind it (hitable.rs:57-62, material.rs, pbr.rs, texture.rs).  Only Sphere
- * primitives are on the accelerated path (rect/box/medium are §8(f)).
+ * objects behind it (hitable.rs:57-62, material.rs, pbr.rs, texture.rs).  Spheres (SURVEY.md
+ * §8(a) a4) and axis-aligned rectangles / boxes (§8(f) rank 1) are on the accelerated path;
+ * instance transforms (Translate, RotateY) and ConstantMedium are not yet.
  */
 typedef struct RtFlatScene {
     /* spheres: hitable.rs:57-62 `Sphere { c, r, mat, name }` in world-list order */
@@ -92,6 +101,16 @@ typedef struct RtFlatScene {
     const float* sph_cz;
     const float* sph_r;
     const uint32_t* sph_mat; /* [n_spheres] index into the material table */
+
+    /* axis-aligned rectangles: hitable.rs:244-362 `XYRect/XZRect/YZRect { min, max, mat }`; a GBox
+     * (hitable.rs:364-383) flattens to its 6 sides in the order of GBox::new.  Rect i has primitive
+     * index n_spheres + i: rects come after the spheres in the closest-hit tie order (= world-list
+     * order when the scene lists its spheres first, as simple_light_scene does). */
+    uint32_t n_rects;
+    const uint8_t* rect_axis;  /* [n_rects] RtRectAxis: the constant coordinate */
+    const float* rect_min;     /* [3*n_rects] `min` as written in the scene */
+    const float* rect_max;     /* [3*n_rects] `max` */
+    const uint32_t* rect_mat;  /* [n_rects] */
 
     /* materials */
     uint32_t n_materials;
@@ -247,7 +266,7 @@ typedef struct RtBounceIO {
     const float* in_o;         /* [3n] */
     const float* in_d;         /* [3n] */
     const uint32_t* in_key;    /* [2n] per-path RNG key (k0,k1) */
-    int32_t* out_hit;          /* [n] sphere index or -1 */
+    int32_t* out_hit;          /* [n] primitive index (sphere i, or n_spheres + rect i) or -1 */
     float* out_t;              /* [n] */
     float* out_radiance;       /* [3n] emitted or sky term of this segment (untinted) */
     float* out_attenuation;    /* [3n] */

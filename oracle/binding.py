@@ -57,6 +57,8 @@ def load():
     lib.orc_camera_get_ray.argtypes = [C.POINTER(RtCamera), C.c_float, C.c_float, f, f]
     lib.orc_sphere_hit.argtypes = [f, C.c_float, f, f, C.c_float, C.c_float, f]
     lib.orc_sphere_hit.restype = C.c_int
+    lib.orc_rect_hit.argtypes = [C.c_int, f, f, f, f, C.c_float, C.c_float, f]
+    lib.orc_rect_hit.restype = C.c_int
     lib.orc_offset_hit_point.argtypes = [f, f, f]
     lib.orc_reflectance.argtypes = [C.c_float, C.c_float]
     lib.orc_reflectance.restype = C.c_float

@@ -466,13 +466,52 @@ inline bool sphere_hit(const RtFlatScene& fs, int idx, const Ray& r, float t_min
     return true;
 }
 
-/* hitable.rs:117-132 HitableList::hit over the flat sphere list (world order). */
+/* hitable.rs:244-362 XYRect / XZRect / YZRect::hit.  `axis` is the constant coordinate; (a, b) are the
+ * two in-plane axes in the order the reference tests them and builds uv from.  `rec.tang` is NOT written
+ * (hitable.rs:262-269): it keeps whatever an earlier candidate left there. */
+inline bool rect_hit(const RtFlatScene& fs, int ridx, const Ray& r, float t_min, float t_max, HitRecord& rec) {
+    const int axis = fs.rect_axis[ridx];
+    const V3 mn = ld3(fs.rect_min + 3 * ridx), mx = ld3(fs.rect_max + 3 * ridx);
+    float t = (comp(mn, axis) - comp(r.o, axis)) / comp(r.d, axis);
+    if (t < t_min || t > t_max) return false;
+    V3 p = ray_at(r, t);
+    if (axis == RT_RECT_XY) {
+        if (p.x < mn.x || p.x > mx.x || p.y < mn.y || p.y > mx.y) return false;
+    } else if (axis == RT_RECT_XZ) {
+        if (p.x < mn.x || p.x > mx.x || p.z < mn.z || p.z > mx.z) return false;
+    } else {
+        if (p.z < mn.z || p.z > mx.z || p.y < mn.y || p.y > mx.y) return false;
+    }
+    V3 uv = (p - mn) / (mx - mn);
+    rec.uv = axis == RT_RECT_XY ? V2{uv.x, uv.y} : (axis == RT_RECT_XZ ? V2{uv.x, uv.z} : V2{uv.y, uv.z});
+    rec.p = p;
+    rec.t = t;
+    V3 outward_normal = axis == RT_RECT_XY ? v3(0, 0, 1) : (axis == RT_RECT_XZ ? v3(0, 1, 0) : v3(1, 0, 0));
+    set_face_normal(rec, r, outward_normal);
+    rec.mat = (int)fs.rect_mat[ridx];
+    rec.prim = (int)fs.n_spheres + ridx;
+    return true;
+}
+inline AABB rect_bbox(const RtFlatScene& fs, int ridx) { /* hitable.rs:274-278, 314-318, 354-358 */
+    const int axis = fs.rect_axis[ridx];
+    V3 mn = ld3(fs.rect_min + 3 * ridx), mx = ld3(fs.rect_max + 3 * ridx);
+    if (axis == RT_RECT_XY) mn.z = mn.z - 0.0001f, mx.z = mx.z + 0.0001f;
+    else if (axis == RT_RECT_XZ) mn.y = mn.y - 0.0001f, mx.y = mx.y + 0.0001f;
+    else mn.x = mn.x - 0.0001f, mx.x = mx.x + 0.0001f;
+    return AABB{mn, mx};
+}
+/* primitive i: sphere i for i < n_spheres, else rect i - n_spheres (the flat scene's tie order) */
+inline bool prim_hit(const RtFlatScene& fs, int i, const Ray& r, float t_min, float t_max, HitRecord& rec) {
+    return i < (int)fs.n_spheres ? sphere_hit(fs, i, r, t_min, t_max, rec) : rect_hit(fs, i - (int)fs.n_spheres, r, t_min, t_max, rec);
+}
+
+/* hitable.rs:117-132 HitableList::hit over the flat primitive list (world order). */
 inline bool list_hit(const RtFlatScene& fs, const Ray& r, float t_min, float t_max, HitRecord& rec) {
     HitRecord temp_rec;
     float closest_so_far = t_max;
     bool hit_anything = false;
-    for (uint32_t i = 0; i < fs.n_spheres; ++i) {
-        if (sphere_hit(fs, (int)i, r, t_min, closest_so_far, temp_rec)) {
+    for (uint32_t i = 0; i < fs.n_spheres + fs.n_rects; ++i) {
+        if (prim_hit(fs, (int)i, r, t_min, closest_so_far, temp_rec)) {
             hit_anything = true;
             closest_so_far = temp_rec.t;
         }
@@ -491,6 +530,7 @@ struct Bvh {
     int root = -1;
 };
 inline AABB sphere_bbox(const RtFlatScene& fs, int idx) { /* hitable.rs:104-108 */
+    if (idx >= (int)fs.n_spheres) return rect_bbox(fs, idx - (int)fs.n_spheres);
     V3 c = v3(fs.sph_cx[idx], fs.sph_cy[idx], fs.sph_cz[idx]);
     float r = fs.sph_r[idx];
     return AABB{c - r, c + r};
@@ -534,7 +574,7 @@ int bvh_build(const RtFlatScene& fs, Bvh& bvh, std::vector<int>& objects, size_t
 }
 bool bvh_hit(const RtFlatScene& fs, const Bvh& bvh, int node, const Ray& r, float t_min, float t_max,
              HitRecord& rec) { /* hitable.rs:232-240 */
-    if (node < 0) return sphere_hit(fs, ~node, r, t_min, t_max, rec);
+    if (node < 0) return prim_hit(fs, ~node, r, t_min, t_max, rec);
     const BvhNode& n = bvh.nodes[(size_t)node];
     if (!aabb_hit(n.box, r, t_min, t_max)) return false;
     bool hit_left = bvh_hit(fs, bvh, n.left, r, t_min, t_max, rec);
@@ -1012,6 +1052,8 @@ static int validate_scene(const RtFlatScene* fs) {
     if (!fs) return RT_ERR_INVALID;
     for (uint32_t i = 0; i < fs->n_spheres; ++i)
         if (fs->sph_mat[i] >= fs->n_materials) return RT_ERR_INVALID;
+    for (uint32_t i = 0; i < fs->n_rects; ++i)
+        if (fs->rect_mat[i] >= fs->n_materials || fs->rect_axis[i] > RT_RECT_XY) return RT_ERR_INVALID;
     return RT_OK;
 }
 
@@ -1042,11 +1084,11 @@ int orc_render(const RtFlatScene* fs, const RtCamera* cam, const RtParams* prm, 
     const size_t nrows = rows.size();
 
     Bvh bvh;
-    if (opt->accel == 1 && fs->n_spheres > 0) {
+    if (opt->accel == 1 && fs->n_spheres + fs->n_rects > 0) {
         Xoshiro256pp main_rng = smallrng_seed_from_u64(opt->bvh_seed);
         for (uint32_t k = 0; k < opt->bvh_skip_perlin; ++k) perlin_default(main_rng, nullptr, nullptr);
-        std::vector<int> objects(fs->n_spheres);
-        for (uint32_t i = 0; i < fs->n_spheres; ++i) objects[i] = (int)i;
+        std::vector<int> objects(fs->n_spheres + fs->n_rects);
+        for (uint32_t i = 0; i < fs->n_spheres + fs->n_rects; ++i) objects[i] = (int)i;
         bvh.root = bvh_build(*fs, bvh, objects, 0, objects.size(), main_rng);
     }
 
@@ -1148,10 +1190,10 @@ int orc_render(const RtFlatScene* fs, const RtCamera* cam, const RtParams* prm, 
 int orc_debug_bounce(const RtFlatScene* fs, const RtBounceIO* io, uint32_t accel) {
     if (validate_scene(fs) != RT_OK || !io) return RT_ERR_INVALID;
     Bvh bvh;
-    if (accel == 1 && fs->n_spheres > 0) {
+    if (accel == 1 && fs->n_spheres + fs->n_rects > 0) {
         Xoshiro256pp main_rng = smallrng_seed_from_u64(1995);
-        std::vector<int> objects(fs->n_spheres);
-        for (uint32_t i = 0; i < fs->n_spheres; ++i) objects[i] = (int)i;
+        std::vector<int> objects(fs->n_spheres + fs->n_rects);
+        for (uint32_t i = 0; i < fs->n_spheres + fs->n_rects; ++i) objects[i] = (int)i;
         bvh.root = bvh_build(*fs, bvh, objects, 0, objects.size(), main_rng);
     }
     Ctx cx;
@@ -1250,6 +1292,24 @@ int orc_sphere_hit(const float c[3], float rad, const float o[3], const float d[
     out[13] = 0.0f;
     return 1;
 }
+/* XYRect/XZRect/YZRect::hit on a single rectangle: returns 1/0, fills t,p,n,front,uv (10 floats) */
+int orc_rect_hit(int axis, const float mn[3], const float mx[3], const float o[3], const float d[3], float t_min, float t_max,
+                 float out[10]) {
+    RtFlatScene fs;
+    std::memset(&fs, 0, sizeof(fs));
+    uint8_t ax = (uint8_t)axis;
+    uint32_t mat = 0;
+    fs.n_rects = 1, fs.rect_axis = &ax, fs.rect_min = mn, fs.rect_max = mx, fs.rect_mat = &mat;
+    HitRecord rec;
+    Ray r{ld3(o), ld3(d)};
+    if (!rect_hit(fs, 0, r, t_min, t_max, rec)) return 0;
+    out[0] = rec.t;
+    out[1] = rec.p.x, out[2] = rec.p.y, out[3] = rec.p.z;
+    out[4] = rec.norm.x, out[5] = rec.norm.y, out[6] = rec.norm.z;
+    out[7] = rec.front_face ? 1.0f : 0.0f;
+    out[8] = rec.uv.x, out[9] = rec.uv.y;
+    return 1;
+}
 void orc_offset_hit_point(const float p[3], const float n[3], float out[3]) {
     V3 r = offset_hit_point(ld3(p), ld3(n));
     out[0] = r.x, out[1] = r.y, out[2] = r.z;
@@ -1326,8 +1386,8 @@ uint32_t orc_bvh_stats(const RtFlatScene* fs, uint64_t seed, uint32_t skip_perli
     Bvh bvh;
     Xoshiro256pp main_rng = smallrng_seed_from_u64(seed);
     for (uint32_t k = 0; k < skip_perlin; ++k) perlin_default(main_rng, nullptr, nullptr);
-    std::vector<int> objects(fs->n_spheres);
-    for (uint32_t i = 0; i < fs->n_spheres; ++i) objects[i] = (int)i;
+    std::vector<int> objects(fs->n_spheres + fs->n_rects);
+    for (uint32_t i = 0; i < fs->n_spheres + fs->n_rects; ++i) objects[i] = (int)i;
     bvh.root = bvh_build(*fs, bvh, objects, 0, objects.size(), main_rng);
     if (n_nodes) *n_nodes = (uint32_t)bvh.nodes.size();
     return (uint32_t)bvh.root;

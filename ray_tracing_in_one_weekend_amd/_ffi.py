@@ -24,6 +24,8 @@ RTH_INVALID = 0xFFFFFFFF
  MAT_DISNEY_CLEARCOAT) = range(13)
 # enum RtTexType
 TEX_CONSTANT, TEX_CHECKER, TEX_PERLIN, TEX_IMAGE = range(4)
+# enum RtRectAxis
+RECT_YZ, RECT_XZ, RECT_XY = range(3)
 # enum RtSkyType
 SKY_GRADIENT, SKY_BLACK, SKY_ENV = range(3)
 
@@ -38,6 +40,8 @@ class RtFlatScene(C.Structure):
     _fields_ = [
         ("n_spheres", C.c_uint32),
         ("sph_cx", _f), ("sph_cy", _f), ("sph_cz", _f), ("sph_r", _f), ("sph_mat", _u32),
+        ("n_rects", C.c_uint32),
+        ("rect_axis", _u8), ("rect_min", _f), ("rect_max", _f), ("rect_mat", _u32),
         ("n_materials", C.c_uint32),
         ("mat_type", _u8), ("mat_color", _f), ("mat_p0", _f), ("mat_p1", _f), ("mat_p2", _f), ("mat_p3", _f),
         ("mat_tex0", _u32), ("mat_tex1", _u32),
@@ -86,7 +90,7 @@ GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_err
                "rt_get_depth_timings"]
 HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
                 "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
-                "rth_sphere", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
+                "rth_sphere", "rth_rect", "rth_gbox", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
                 "rth_scene_camera", "rth_scene_sphere_name", "rth_scene_free"]
 
 _gpu_lib = None
@@ -164,6 +168,10 @@ def load_host_library():
     lib.rth_material.restype = C.c_uint32
     lib.rth_sphere.argtypes = [vp, f3, C.c_float, C.c_uint32, C.c_char_p]
     lib.rth_sphere.restype = C.c_uint32
+    lib.rth_rect.argtypes = [vp, C.c_uint32, f3, f3, C.c_uint32]
+    lib.rth_rect.restype = C.c_uint32
+    lib.rth_gbox.argtypes = [vp, f3, f3, C.c_uint32]
+    lib.rth_gbox.restype = C.c_uint32
     lib.rth_set_sky.argtypes = [vp, C.c_uint32, C.c_char_p]
     lib.rth_set_sky.restype = C.c_int
     lib.rth_set_camera.argtypes = [vp, f3, f3, f3, C.c_float, C.c_float]

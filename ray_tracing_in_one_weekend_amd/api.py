@@ -72,6 +72,12 @@ class Scene:
     def sphere(self, c, r, material, name=""):
         return self._check(self._lib.rth_sphere(self._h, _f3(c), C.c_float(r), material, name.encode()))
 
+    def rect(self, axis, mn, mx, material):
+        return self._check(self._lib.rth_rect(self._h, axis, _f3(mn), _f3(mx), material))
+
+    def gbox(self, mn, mx, material):
+        return self._check(self._lib.rth_gbox(self._h, _f3(mn), _f3(mx), material))
+
     def set_sky(self, sky, env_path=None):
         if self._lib.rth_set_sky(self._h, sky, env_path.encode() if env_path else None) != 0:
             raise RtError(self._lib.rth_last_error().decode())
@@ -124,6 +130,8 @@ class Scene:
             "sph_cx": arr(fs.sph_cx, ns, np.float32), "sph_cy": arr(fs.sph_cy, ns, np.float32),
             "sph_cz": arr(fs.sph_cz, ns, np.float32), "sph_r": arr(fs.sph_r, ns, np.float32),
             "sph_mat": arr(fs.sph_mat, ns, np.uint32),
+            "rect_axis": arr(fs.rect_axis, fs.n_rects, np.uint8), "rect_min": arr(fs.rect_min, 3 * fs.n_rects, np.float32),
+            "rect_max": arr(fs.rect_max, 3 * fs.n_rects, np.float32), "rect_mat": arr(fs.rect_mat, fs.n_rects, np.uint32),
             "mat_type": arr(fs.mat_type, nm, np.uint8), "mat_color": arr(fs.mat_color, 3 * nm, np.float32),
             "mat_p0": arr(fs.mat_p0, nm, np.float32), "mat_p1": arr(fs.mat_p1, nm, np.float32),
             "mat_p2": arr(fs.mat_p2, nm, np.float32), "mat_p3": arr(fs.mat_p3, nm, np.float32),

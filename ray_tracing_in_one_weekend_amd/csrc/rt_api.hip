@@ -211,6 +211,17 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     for (uint32_t i = 0; i < s->n_spheres; ++i)
         if (s->sph_mat[i] >= s->n_materials)
             return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: sphere " + std::to_string(i) + " has material index out of range");
+    if (s->n_rects && (!s->rect_axis || !s->rect_min || !s->rect_max || !s->rect_mat))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: rectangle arrays missing");
+    for (uint32_t i = 0; i < s->n_rects; ++i) {
+        if (s->rect_axis[i] > RT_RECT_XY) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: unknown rectangle axis");
+        if (s->rect_mat[i] >= s->n_materials)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: rectangle " + std::to_string(i) + " has material index out of range");
+        // DisneyMetal reads rec.tang, which a rectangle never writes (hitable.rs:262-269): the reference then uses
+        // whatever an earlier candidate left in the record — not reproducible outside its traversal order
+        if (s->mat_type[s->rect_mat[i]] == RT_MAT_DISNEY_METAL)
+            return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: DisneyMetal on a rectangle reads a stale HitRecord.tang in the reference");
+    }
     for (uint32_t m = 0; m < s->n_materials; ++m) {
         uint32_t t = s->mat_type[m];
         if (t >= RT_MAT__COUNT) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: unknown material type");
@@ -284,27 +295,49 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         for (size_t p = 0; p < np; ++p) texels[off + p] = make_float4(src[3 * p], src[3 * p + 1], src[3 * p + 2], 0.0f);
     }
 
-    HostBvh bvh;
-    build_sphere_bvh(geo, RT_BVH_MAX_DEPTH, bvh);
-    std::vector<uint8_t> sclass(s->n_spheres);
-    std::vector<float4> srec((size_t)s->n_spheres * 4);
+    // rectangles: device geometry (k, u0, u1, v0), (v1, axis) with (u, v) the uv axes of hitable.rs:262-263 etc.
+    const uint32_t n_prims = s->n_spheres + s->n_rects;
+    std::vector<float4> rgeo((size_t)s->n_rects * 2);
+    std::vector<PrimBox> pboxes(n_prims);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const float c[3] = {geo[i].x, geo[i].y, geo[i].z};
+        const float r = std::fabs(geo[i].w);
+        for (int k = 0; k < 3; ++k) pboxes[i].mn[k] = c[k] - r, pboxes[i].mx[k] = c[k] + r;
+    }
     auto fbits = [](uint32_t u) {
         float f;
         std::memcpy(&f, &u, 4);
         return f;
     };
-    for (uint32_t i = 0; i < s->n_spheres; ++i) {
-        const uint32_t m = s->sph_mat[i], ty = s->mat_type[m];
+    for (uint32_t i = 0; i < s->n_rects; ++i) {
+        const uint32_t ax = s->rect_axis[i];
+        const float* mn = s->rect_min + 3 * (size_t)i;
+        const float* mx = s->rect_max + 3 * (size_t)i;
+        const int ua = ax == 0 ? 1 : 0, va = ax == 2 ? 1 : 2;
+        rgeo[2 * (size_t)i] = make_float4(mn[ax], mn[ua], mx[ua], mn[va]);
+        rgeo[2 * (size_t)i + 1] = make_float4(mx[va], fbits(ax), 0.0f, 0.0f);
+        PrimBox& b = pboxes[s->n_spheres + i];
+        for (int k = 0; k < 3; ++k) b.mn[k] = std::min(mn[k], mx[k]), b.mx[k] = std::max(mn[k], mx[k]);
+        b.mn[ax] = mn[ax] - 0.0001f, b.mx[ax] = mn[ax] + 0.0001f; // the plane the hit test uses (hitable.rs:253)
+    }
+    HostBvh bvh;
+    build_prim_bvh(pboxes, RT_BVH_MAX_DEPTH, bvh);
+    std::vector<uint8_t> sclass(n_prims);
+    std::vector<float4> srec((size_t)n_prims * 5);
+    for (uint32_t i = 0; i < n_prims; ++i) {
+        const bool is_rect = i >= s->n_spheres;
+        const uint32_t m = is_rect ? s->rect_mat[i - s->n_spheres] : s->sph_mat[i], ty = s->mat_type[m];
         const bool has_t0 = mat_needs_tex0(ty) && s->mat_tex0[m] < s->n_textures;
         const uint32_t t0 = has_t0 ? s->mat_tex0[m] : 0u;
         const uint32_t tt = has_t0 ? s->tex_type[t0] : 0u;
         sclass[i] = (uint8_t)(1u + ty * 4u + tt); // < RT_NCLASS
         // colour slot: the texture's colour 0 for textured materials, the albedo for Metal
         const float* col = has_t0 ? s->tex_color0 + 3 * (size_t)t0 : s->mat_color + 3 * (size_t)m;
-        srec[4 * (size_t)i + 0] = geo[i];
-        srec[4 * (size_t)i + 1] = make_float4(fbits(ty), fbits(tt), fbits(has_t0 ? s->tex_aux[t0] : 0u), fbits(s->mat_tex1[m]));
-        srec[4 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], s->mat_p0[m]);
-        srec[4 * (size_t)i + 3] = make_float4(s->mat_p1[m], s->mat_p2[m], has_t0 ? s->tex_scale[t0] : 0.0f, fbits(s->mat_tex0[m]));
+        srec[5 * (size_t)i + 0] = is_rect ? rgeo[2 * (size_t)(i - s->n_spheres)] : geo[i];
+        srec[5 * (size_t)i + 1] = make_float4(fbits(ty), fbits(tt), fbits(has_t0 ? s->tex_aux[t0] : 0u), fbits(s->mat_tex1[m]));
+        srec[5 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], s->mat_p0[m]);
+        srec[5 * (size_t)i + 3] = make_float4(s->mat_p1[m], s->mat_p2[m], has_t0 ? s->tex_scale[t0] : 0.0f, fbits(s->mat_tex0[m]));
+        srec[5 * (size_t)i + 4] = is_rect ? rgeo[2 * (size_t)(i - s->n_spheres) + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     HostBvh4 bvh4;
@@ -313,6 +346,8 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
     DevScene ds{};
+    ds.n_rects = s->n_rects;
+    ds.n_prims = n_prims;
     ds.n_bvh4_nodes = (uint32_t)bvh4.id.size();
     ds.bvh4_depth = bvh4.depth;
     ds.n_spheres = s->n_spheres, ds.n_materials = s->n_materials, ds.n_textures = s->n_textures;
@@ -321,7 +356,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     if ((rc = upload(ctx, geo, &ds.sph_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
         (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
-        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
+        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, rgeo, &ds.rect_geo)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
         (rc = upload(ctx, bvh4.p[0], &ds.bvh4_p[0])) || (rc = upload(ctx, bvh4.p[1], &ds.bvh4_p[1])) ||
         (rc = upload(ctx, bvh4.p[2], &ds.bvh4_p[2])) || (rc = upload(ctx, bvh4.p[3], &ds.bvh4_p[3])) ||
         (rc = upload(ctx, bvh4.p[4], &ds.bvh4_p[4])) || (rc = upload(ctx, bvh4.p[5], &ds.bvh4_p[5]))) {
@@ -332,13 +367,15 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     ctx->has_scene = true;
     // k_intersect keeps nodes + spheres + one u16 stack column per lane in LDS
     ctx->isect_lds = bvh_lds_bytes(ds, RT_BVH_BLOCK);
-    ctx->use_bvh = ds.n_spheres > 0 && ds.n_bvh4_nodes > 0 && ds.n_bvh4_nodes < 32768 && ds.n_spheres <= 32768 &&
+    ctx->use_bvh = ds.n_prims > 0 && ds.n_bvh4_nodes > 0 && ds.n_bvh4_nodes < 32768 && ds.n_prims <= 32768 &&
                    bvh.depth <= RT_BVH_MAX_DEPTH && ctx->isect_lds <= ctx->lds_limit;
     if (ctx->use_bvh) {
-        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
-        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
+        const void* isect_variants[4] = {reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, false>),
+                                         reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true>),
+                                         reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, false>),
+                                         reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true>)};
+        for (const void* fn : isect_variants)
+            RT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
         RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
     }
@@ -429,7 +466,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
 
     const size_t list_lds = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
     const bool perlin_lds = ctx->ds.n_perlin > 0 && ctx->ds.n_perlin <= RT_PERLIN_LDS_MAX_SETS;
-    const size_t shade_lds = shade_lds_bytes(ctx->ds.n_spheres, perlin_lds ? ctx->ds.n_perlin : 0u);
+    const size_t shade_lds = shade_lds_bytes(ctx->ds.n_prims, perlin_lds ? ctx->ds.n_perlin : 0u);
     if (shade_lds > 64u * 1024u) return fail(ctx, RT_ERR_UNSUPPORTED, "render: scene has too many spheres for the k_shade class table");
 
     RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
@@ -459,6 +496,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         }
     }
     const IntersectParams ip{nq, cap};
+    const bool rects = ctx->ds.n_rects > 0; // selects the kernel instantiations with the rectangle branches
     for (uint32_t sl = 0; sl < n_slices; ++sl) {
         const uint32_t s0 = sl * S;
         const uint32_t sc = std::min(S, spp - s0);
@@ -476,24 +514,32 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             const bool td = time_depths && sl == 0;
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth], st));
             const bool gen = fuse_gen && depth == 0;
-            if (use_bvh && gen)
-                hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, true>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds,
-                                   qi.a, qi.b, qhit, cin, ip, gpd);
-            else if (use_bvh)
-                hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, false>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds,
-                                   qi.a, qi.b, qhit, cin, ip, gpd);
+#define RT_LAUNCH_ISECT(G, R)                                                                                          \
+    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, \
+                       qi.a, qi.b, qhit, cin, ip, gpd)
+            if (use_bvh && gen && rects) RT_LAUNCH_ISECT(true, true);
+            else if (use_bvh && gen) RT_LAUNCH_ISECT(true, false);
+            else if (use_bvh && rects) RT_LAUNCH_ISECT(false, true);
+            else if (use_bvh) RT_LAUNCH_ISECT(false, false);
+#undef RT_LAUNCH_ISECT
             else
                 hipLaunchKernelGGL(k_intersect_list, dim3(nq), dim3(256), list_lds, st, ctx->ds, qi.a, qi.b, qhit, cin, ip);
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth + 1], st));
             // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
             const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u,
                                  (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u};
-#define RT_LAUNCH_SHADE(P, G) \
-    hipLaunchKernelGGL((k_shade<P, G>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals, gpd)
-            if (perlin_lds && gen) RT_LAUNCH_SHADE(true, true);
-            else if (perlin_lds) RT_LAUNCH_SHADE(true, false);
-            else if (gen) RT_LAUNCH_SHADE(false, true);
-            else RT_LAUNCH_SHADE(false, false);
+#define RT_LAUNCH_SHADE(P, G, R) \
+    hipLaunchKernelGGL((k_shade<P, G, R>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals, gpd)
+#define RT_LAUNCH_SHADE_R(P, G)        \
+    do {                               \
+        if (rects) RT_LAUNCH_SHADE(P, G, true); \
+        else RT_LAUNCH_SHADE(P, G, false);      \
+    } while (0)
+            if (perlin_lds && gen) RT_LAUNCH_SHADE_R(true, true);
+            else if (perlin_lds) RT_LAUNCH_SHADE_R(true, false);
+            else if (gen) RT_LAUNCH_SHADE_R(false, true);
+            else RT_LAUNCH_SHADE_R(false, false);
+#undef RT_LAUNCH_SHADE_R
 #undef RT_LAUNCH_SHADE
             n_trace_launches += 2;
         }

@@ -1,11 +1,11 @@
-// rt_bvh.h — host-side builder of the sphere BVH that the trace kernel stages into LDS.
+// rt_bvh.h — host-side builder of the primitive (sphere / rectangle) BVH that k_intersect stages into LDS.
 //
 // The reference accelerates closest-hit with a random-axis median-split BVH of trait objects
 // (hitable.rs:158-241).  The GPU path keeps the RESULT of HitableList::hit (hitable.rs:117-132:
 // the closest root, ties to the later sphere) but searches with its own structure: a binned-SAH
 // BVH2 whose nodes hold both child boxes (one LDS fetch per visit decides both children),
-// single-sphere leaves, boxes padded so that culling is conservative with respect to the exact
-// Sphere::hit arithmetic.  Culling never changes which sphere wins, so results are identical to
+// single-primitive leaves, boxes padded so that culling is conservative with respect to the exact
+// Sphere::hit / XYRect::hit arithmetic.  Culling never changes which sphere wins, so results are identical to
 // the brute-force list walk (tests/test_gpu_parity.py::test_bvh_equals_brute_force).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -18,6 +18,11 @@
 #include <vector>
 
 namespace rt {
+
+// tight axis-aligned bounds of one primitive (before padding)
+struct PrimBox {
+    float mn[3], mx[3];
+};
 
 struct HostBvh {
     std::vector<float4> a, b, c;
@@ -50,27 +55,29 @@ struct Box {
 };
 
 struct Builder {
-    const std::vector<float4>& geo;
-    std::vector<Box> boxes;     // padded sphere boxes
+    std::vector<Box> boxes;     // padded primitive boxes
+    std::vector<float> cen;     // 3 per primitive: box centres (the SAH binning key)
     std::vector<uint32_t> order;
     HostBvh& out;
     bool median_only;
 
-    Builder(const std::vector<float4>& g, HostBvh& o, bool median) : geo(g), out(o), median_only(median) {
-        boxes.resize(g.size());
-        order.resize(g.size());
-        for (size_t i = 0; i < g.size(); ++i) {
+    // `prim` = tight primitive bounds (sphere: c -+ r; rectangle: its plane slab)
+    Builder(const std::vector<PrimBox>& prim, HostBvh& o, bool median) : out(o), median_only(median) {
+        boxes.resize(prim.size());
+        cen.resize(prim.size() * 3);
+        order.resize(prim.size());
+        for (size_t i = 0; i < prim.size(); ++i) {
             order[i] = (uint32_t)i;
-            const float c[3] = {g[i].x, g[i].y, g[i].z};
-            const float r = std::fabs(g[i].w);
             for (int k = 0; k < 3; ++k) {
-                // pad: 2^-18 of the coordinate magnitude, >= 10x the fp32 error of the exact test
-                float pad = (std::fabs(c[k]) + r) * 3.8146973e-06f + 1e-30f;
-                boxes[i].mn[k] = c[k] - r - pad;
-                boxes[i].mx[k] = c[k] + r + pad;
-                if (!(boxes[i].mn[k] <= boxes[i].mx[k])) { // NaN/inf sphere: never cull it
+                // pad: 2^-18 of the coordinate magnitude, >= 10x the fp32 error of the exact tests
+                const float mag = std::max(std::fabs(prim[i].mn[k]), std::fabs(prim[i].mx[k]));
+                const float pad = mag * 3.8146973e-06f + 1e-30f;
+                boxes[i].mn[k] = prim[i].mn[k] - pad;
+                boxes[i].mx[k] = prim[i].mx[k] + pad;
+                if (!(boxes[i].mn[k] <= boxes[i].mx[k])) { // NaN/inf primitive: never cull it
                     boxes[i].mn[k] = -FLT_MAX, boxes[i].mx[k] = FLT_MAX;
                 }
+                cen[3 * i + (size_t)k] = 0.5f * prim[i].mn[k] + 0.5f * prim[i].mx[k];
             }
         }
     }
@@ -89,15 +96,14 @@ struct Builder {
         // centroid bounds
         float cmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
         for (size_t i = first; i < first + count; ++i) {
-            const float4& g = geo[order[i]];
-            const float c[3] = {g.x, g.y, g.z};
+            const float* c = &cen[3 * (size_t)order[i]];
             for (int k = 0; k < 3; ++k) cmn[k] = std::min(cmn[k], c[k]), cmx[k] = std::max(cmx[k], c[k]);
         }
         int axis = 0;
         float ext = cmx[0] - cmn[0];
         for (int k = 1; k < 3; ++k)
             if (cmx[k] - cmn[k] > ext) ext = cmx[k] - cmn[k], axis = k;
-        auto cen = [&](uint32_t id) { return axis == 0 ? geo[id].x : (axis == 1 ? geo[id].y : geo[id].z); };
+        auto cen = [&](uint32_t id) { return this->cen[3 * (size_t)id + (size_t)axis]; };
         size_t mid = first + count / 2;
         bool done = false;
         if (!median_only && ext > 0.0f && count > 2) {
@@ -161,10 +167,10 @@ struct Builder {
 
 } // namespace bvh_detail
 
-// Builds the BVH for `geo` = (cx, cy, cz, r).  The root is always inner node 0 (a single sphere
-// gets an empty right child).  `max_depth` bounds the traversal stack: if the SAH tree is deeper,
-// a median-split tree (depth <= ceil(log2 n) + 1) is built instead.
-inline void build_sphere_bvh(const std::vector<float4>& geo, uint32_t max_depth, HostBvh& out) {
+// Builds the BVH over primitive bounds.  The root is always inner node 0 (a single primitive gets
+// an empty right child).  `max_depth` bounds the traversal stack: if the SAH tree is deeper, a
+// median-split tree (depth <= ceil(log2 n) + 1) is built instead.
+inline void build_prim_bvh(const std::vector<PrimBox>& geo, uint32_t max_depth, HostBvh& out) {
     out = HostBvh();
     if (geo.empty()) return;
     if (geo.size() == 1) {

@@ -174,6 +174,9 @@ struct ImgRec { // 16 B
     uint32_t offset_lo, offset_hi; // offset in texels into the float4 texel pool
 };
 struct DevScene {
+    uint32_t n_rects;   // axis-aligned rectangles; primitive index = n_spheres + rect index
+    uint32_t n_prims;   // n_spheres + n_rects
+    const float4* rect_geo; // 2 per rect: (k, u0, u1, v0), (v1, axis bits, 0, 0); (u, v) = uv axes of the rect
     uint32_t n_spheres;
     uint32_t n_materials;
     uint32_t n_textures;
@@ -197,12 +200,13 @@ struct DevScene {
     uint32_t bvh4_depth;
     const float4* bvh4_p[6];
     const int4* bvh4_id;
-    // shading class of every sphere (1 + material_type*4 + texture_type of tex0; 0 is "miss"):
+    // shading class of every primitive (1 + material_type*4 + texture_type of tex0; 0 is "miss"):
     // k_shade sorts the rays of a chunk by class so that a wave runs one material branch
     const uint8_t* sph_class;
-    // Per-sphere shading record, 4 x float4 (one dependent fetch after the hit index instead of
-    // sphere -> material -> texture):  [0] cx cy cz r   [1] type, tex0 type, tex0 aux, tex1 (u32 bits)
-    // [2] colour (ConstantTex / Checker odd / Metal albedo) rgb, p0   [3] p1, p2, tex0 scale, tex0 (u32 bits)
+    // Per-primitive shading record, 5 x float4 (one dependent fetch after the hit index instead of
+    // primitive -> material -> texture):  [0] sphere: cx cy cz r / rect: k u0 u1 v0
+    // [1] type, tex0 type, tex0 aux, tex1 (u32 bits)   [2] colour (ConstantTex / Checker odd / Metal albedo) rgb, p0
+    // [3] p1, p2, tex0 scale, tex0 (u32 bits)   [4] rect: v1, axis bits
     const float4* sph_rec;
 };
 
@@ -264,7 +268,8 @@ __device__ inline V3 image_value(const DevScene& sc, uint32_t img, V2 uv, uint32
     return v3(t.x, t.y, t.z);
 }
 // `on` = outward unit normal of the hit sphere, from which rec.uv is derived lazily (hitable.rs:98)
-__device__ inline V3 texture_value(const DevScene& sc, const PerlinTables& pt, uint32_t tex, V3 on, V3 p, uint32_t& n_fetch) {
+__device__ inline V3 texture_value(const DevScene& sc, const PerlinTables& pt, uint32_t tex, V3 on, bool is_rect, V2 rect_uv,
+                                   V3 p, uint32_t& n_fetch) {
     TexRec tr = sc.texs[tex];
     switch (tr.type) {
     case 0: // ConstantTex texture.rs:19-23
@@ -278,14 +283,16 @@ __device__ inline V3 texture_value(const DevScene& sc, const PerlinTables& pt, u
         return (s + 1.0f) * 0.5f * splat(1.0f);
     }
     default: // ImageTex
-        return image_value(sc, tr.aux, sphere_get_uv(on), n_fetch);
+        return image_value(sc, tr.aux, is_rect ? rect_uv : sphere_get_uv(on), n_fetch);
     }
 }
 
 // Texture::value for the material's first texture, described inline by the sphere record
 // (type, aux, scale, colour 0); only CheckerTex needs its second colour from the TexRec table.
+// `is_rect`: rec.uv is the rectangle's (p - min)/(max - min) instead of Sphere::get_uv(on).
 __device__ inline V3 texture_value_inline(const DevScene& sc, const PerlinTables& pt, uint32_t ttype, uint32_t taux,
-                                          float scale, V3 c0, uint32_t tex, V3 on, V3 p, uint32_t& n_fetch) {
+                                          float scale, V3 c0, uint32_t tex, V3 on, bool is_rect, V2 rect_uv, V3 p,
+                                          uint32_t& n_fetch) {
     switch (ttype) {
     case 0: // ConstantTex texture.rs:19-23
         return c0;
@@ -300,7 +307,7 @@ __device__ inline V3 texture_value_inline(const DevScene& sc, const PerlinTables
         return (s + 1.0f) * 0.5f * splat(1.0f);
     }
     default: // ImageTex
-        return image_value(sc, taux, sphere_get_uv(on), n_fetch);
+        return image_value(sc, taux, is_rect ? rect_uv : sphere_get_uv(on), n_fetch);
     }
 }
 
@@ -389,6 +396,24 @@ __device__ __forceinline__ bool sphere_root(float4 g, V3 o, V3 d, float a, float
     return true;
 }
 
+// hitable.rs:244-362 XYRect/XZRect/YZRect::hit up to the accepted t.  g0 = (k, u0, u1, v0), g1 = (v1, axis):
+// axis 0: x = k, (u,v) = (y,z); axis 1: y = k, (u,v) = (x,z); axis 2: z = k, (u,v) = (x,y).
+// A NaN t (ray inside the plane: 0/0) is rejected here; the reference's comparisons all fail on it and
+// report a hit with t = NaN (documented deviation, measure zero).
+__device__ __forceinline__ bool rect_root(float4 g0, float4 g1, V3 o, V3 d, float t_min, float t_max, float& t_hit) {
+    const uint32_t axis = __float_as_uint(g1.y);
+    const float oa = axis == 0u ? o.x : (axis == 1u ? o.y : o.z);
+    const float da = axis == 0u ? d.x : (axis == 1u ? d.y : d.z);
+    const float t = (g0.x - oa) / da;
+    if (!(t == t) || t < t_min || t > t_max) return false;
+    const V3 p = o + d * t; // Ray::at
+    const float pu = axis == 0u ? p.y : p.x;
+    const float pv = axis == 2u ? p.y : p.z;
+    if (pu < g0.y || pu > g0.z || pv < g0.w || pv > g1.x) return false;
+    t_hit = t;
+    return true;
+}
+
 // Result of one bounce for one ray.
 struct Bounce {
     V3 radiance;    // emitted (hit) or sky (miss) term of this segment, untinted
@@ -400,6 +425,8 @@ struct Bounce {
 // main.rs:44-58 for one segment whose closest hit is already known.
 // hit < 0: miss -> sky.  Otherwise rebuild the HitRecord (hitable.rs:93-99) and run
 // emitted + scatter of the material (material.rs, pbr.rs).
+// RECTS = false compiles the rectangle branches out (scenes without rectangles: 2 % faster).
+template <bool RECTS>
 __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro, V3 rd, int hit, float t, Rng& rng,
                                uint32_t& n_fetch) {
     Bounce out;
@@ -412,10 +439,22 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         out.radiance = sky_value(sc, rd, n_fetch); // main.rs:58
         return out;
     }
-    const float4* rec = sc.sph_rec + 4u * (uint32_t)hit;
+    const float4* rec = sc.sph_rec + 5u * (uint32_t)hit;
     const float4 g = rec[0], r1 = rec[1];
+    const bool is_rect = RECTS && (uint32_t)hit >= sc.n_spheres;
     V3 p = ro + rd * t;                                 // math.rs:64 Ray::at
-    V3 on = (p - v3(g.x, g.y, g.z)) / g.w;              // hitable.rs:95 outward_normal
+    V3 on;
+    V2 rect_uv = V2{0.0f, 0.0f};
+    if (is_rect) { // hitable.rs:262-268 (and the XZ / YZ twins): uv = (p - min)/(max - min), normal = +axis
+        const float4 g1 = rec[4];
+        const uint32_t axis = __float_as_uint(g1.y);
+        const float pu = axis == 0u ? p.y : p.x;
+        const float pv = axis == 2u ? p.y : p.z;
+        rect_uv = V2{(pu - g.y) / (g.z - g.y), (pv - g.w) / (g1.x - g.w)};
+        on = v3(axis == 0u ? 1.0f : 0.0f, axis == 1u ? 1.0f : 0.0f, axis == 2u ? 1.0f : 0.0f);
+    } else {
+        on = (p - v3(g.x, g.y, g.z)) / g.w;             // hitable.rs:95 outward_normal
+    }
     bool front_face = dot(rd, on) < 0.0f;               // hitable.rs:26
     V3 n = front_face ? on : -on;                       // hitable.rs:27-31
     // the material fields are fetched where a branch needs them (keeps the live set small)
@@ -439,7 +478,8 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
                                 (1u << 10) | (1u << 11);
     V3 tex0_value = splat(0.0f);
     if ((TEX0_USERS >> m.type) & 1u)
-        tex0_value = texture_value_inline(sc, pt, t0type, t0aux, rec[3].z, m.color(), __float_as_uint(rec[3].w), on, p, n_fetch);
+        tex0_value = texture_value_inline(sc, pt, t0type, t0aux, rec[3].z, m.color(), __float_as_uint(rec[3].w), on, is_rect,
+                                          rect_uv, p, n_fetch);
 #define RT_TEX0() tex0_value
     switch (m.type) {
     case 0: // Emission material.rs:21-28
@@ -534,7 +574,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         float h_dot_i = dot(h, -rd);
         float h_dot_o = dot(h, dir_o);
         float n_dot_h = dot(n, h);
-        V3 kd = texture_value(sc, pt, m.tex1, on, p, n_fetch);
+        V3 kd = texture_value(sc, pt, m.tex1, on, is_rect, rect_uv, p, n_fetch);
         V3 ks = RT_TEX0();
         float roughness = clampf(m.p0(), 0.01f, 1.0f);
         float eta = m.p1();

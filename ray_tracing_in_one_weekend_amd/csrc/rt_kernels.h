@@ -131,6 +131,17 @@ __device__ __forceinline__ void closest_hit_tile(const float4* s_geo, uint32_t n
     }
 }
 
+// The rectangles of the list walk (they follow the spheres in the tie order), read from HBM.
+__device__ __forceinline__ void closest_hit_rects(const DevScene& sc, V3 o, V3 d, float& tbest, int& hit) {
+    for (uint32_t r = 0; r < sc.n_rects; ++r) {
+        float th;
+        if (rect_root(sc.rect_geo[2u * r], sc.rect_geo[2u * r + 1u], o, d, 1e-3f, tbest, th)) {
+            tbest = th;
+            hit = (int)(sc.n_spheres + r);
+        }
+    }
+}
+
 #define RT_BVH_BLOCK 1024 // threads per workgroup of k_intersect (one LDS copy of the tree)
 #define RT_BVH_MAX_DEPTH 64u
 #ifndef RT_REFILL_MIN
@@ -144,13 +155,15 @@ __device__ __forceinline__ void closest_hit_tile(const float4* s_geo, uint32_t n
 // to 3 children, so 3 levels per tree level), 16 B of counters.
 __host__ __device__ inline uint32_t bvh_stack_levels(const DevScene& sc) { return 3u * (sc.bvh4_depth ? sc.bvh4_depth : 1u) + 1u; }
 __host__ __device__ inline size_t bvh_lds_bytes(const DevScene& sc, uint32_t block) {
-    return (size_t)sc.n_bvh4_nodes * 112u + (size_t)sc.n_spheres * 16u + (size_t)block * bvh_stack_levels(sc) * 2u + 16u;
+    return (size_t)sc.n_bvh4_nodes * 112u + ((size_t)sc.n_spheres + 2u * sc.n_rects) * 16u +
+           (size_t)block * bvh_stack_levels(sc) * 2u + 16u;
 }
 
 struct BvhLds {
     const float4* pl[6]; // min_x, min_y, min_z, max_x, max_y, max_z of the 4 children
     const int4* id;
-    const float4* geo;
+    const float4* geo;     // spheres (1 float4 each), then rectangles (2 float4 each)
+    uint32_t n_spheres;
     unsigned short* stack; // this lane's column: stack[level * BLOCK]
 };
 
@@ -169,9 +182,11 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
     for (uint32_t i = threadIdx.x; i < n_nodes; i += BLOCK) ids[i] = sc.bvh4_id[i];
     float4* geo = reinterpret_cast<float4*>(ids + n_nodes);
     for (uint32_t i = threadIdx.x; i < n_sph; i += BLOCK) geo[i] = sc.sph_geo[i];
+    for (uint32_t i = threadIdx.x; i < 2u * sc.n_rects; i += BLOCK) geo[n_sph + i] = sc.rect_geo[i];
     L.id = ids;
     L.geo = geo;
-    L.stack = reinterpret_cast<unsigned short*>(geo + n_sph) + threadIdx.x;
+    L.n_spheres = n_sph;
+    L.stack = reinterpret_cast<unsigned short*>(geo + n_sph + 2u * sc.n_rects) + threadIdx.x;
     return L;
 }
 
@@ -192,7 +207,7 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
 // distance — large when the ray is nearly perpendicular to an axis — so the per-ray slack
 // `eps` = 2.4e-7*max|o*inv| (2x the bound for entry + exit) is added to both limits, next to the 4e-6
 // relative widening that covers the rounding of inv and of the fma itself.
-template <int BLOCK>
+template <int BLOCK, bool RECTS>
 __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float nox, float noy,
                                          float noz, float eps, float a, int& cur, int& sp, float& tbest, int& hit) {
     if (cur >= 0) {
@@ -235,8 +250,15 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
     } else {
         const int s = ~cur;
         float th;
-        // candidate root of this sphere (independent of tbest), then the order-independent accept
-        if (sphere_root(L.geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th) && (th < tbest || (th == tbest && s > hit))) {
+        // candidate root of this primitive (independent of tbest), then the order-independent accept
+        bool ok;
+        if (!RECTS || (uint32_t)s < L.n_spheres) {
+            ok = sphere_root(L.geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th);
+        } else {
+            const uint32_t gi = L.n_spheres + 2u * ((uint32_t)s - L.n_spheres);
+            ok = rect_root(L.geo[gi], L.geo[gi + 1u], o, d, 1e-3f, RT_FLT_MAX, th);
+        }
+        if (ok && (th < tbest || (th == tbest && s > hit))) {
             tbest = th;
             hit = s;
         }
@@ -257,7 +279,7 @@ struct IntersectParams {
 // shading code the kernel needs ~40 VGPRs: two 1024-thread workgroups (8 waves per SIMD) share a
 // CU and hide each other's dependent LDS node fetches.
 // GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
-template <int BLOCK, bool GEN>
+template <int BLOCK, bool GEN, bool RECTS>
 __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* __restrict__ qa,
                                                      const float4* __restrict__ qb, float2* __restrict__ qh,
                                                      const uint32_t* __restrict__ in_counts, IntersectParams ip,
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
     if (threadIdx.x == 0) *s_work = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    const bool no_geometry = sc.n_spheres == 0u;
+    const bool no_geometry = sc.n_prims == 0u;
     bool exhausted = false; // wave-uniform: the workgroup has no unclaimed rays left
     bool has = false;
     V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
             if (exhausted) break;
             continue;
         }
-        if (has && bvh_step<BLOCK>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, cur, sp, tbest, hit)) {
+        if (has && bvh_step<BLOCK, RECTS>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, cur, sp, tbest, hit)) {
             qh[pos] = make_float2(tbest, __int_as_float(hit));
             has = false;
         }
@@ -377,6 +399,7 @@ __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float
                 closest_hit_tile(s_geo, n, t0, o, d, a, tbest, hit);
             }
         }
+        closest_hit_rects(sc, o, d, tbest, hit);
         if (active) qh[qbase + i] = make_float2(tbest, __int_as_float(hit));
     }
 }
@@ -410,7 +433,7 @@ __host__ __device__ inline size_t shade_lds_bytes(uint32_t n_spheres, uint32_t n
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
-template <bool PERLIN_LDS, bool GEN>
+template <bool PERLIN_LDS, bool GEN, bool RECTS>
 __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
                                                const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,
                                                float* __restrict__ rad, ShadeParams tp,
@@ -425,8 +448,8 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
     uint32_t* s_offs = s_hist + RT_NCLASS;
     unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_offs + RT_NCLASS);
     uint8_t* s_class = reinterpret_cast<uint8_t*>(s_perm + RT_SORT_N);
-    const uint32_t class_bytes = (sc.n_spheres + 15u) & ~15u;
-    for (uint32_t i = threadIdx.x; i < sc.n_spheres; i += 256u) s_class[i] = sc.sph_class[i];
+    const uint32_t class_bytes = (sc.n_prims + 15u) & ~15u;
+    for (uint32_t i = threadIdx.x; i < sc.n_prims; i += 256u) s_class[i] = sc.sph_class[i];
     PerlinTables pt{sc.perlin_vec, sc.perlin_perm};
     if (PERLIN_LDS) {
         float4* lv = reinterpret_cast<float4*>(s_class + class_bytes);
@@ -507,7 +530,7 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
                     ++n_bad;
                 } else {
                     Rng rng{k0, k1, depth_counter_base(tp.depth)};
-                    bo = shade(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch);
+                    bo = shade<RECTS>(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch);
                     if (bo.alive && tp.russian_roulette) { // main.rs:49-53
                         const float rr = rng.next();
                         rr_threshold = fmaxf(bo.attenuation.x, fmaxf(bo.attenuation.y, bo.attenuation.z)); // max_element
@@ -629,12 +652,12 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
     if (USE_BVH) {
         const BvhLds L = stage_bvh<BLOCK>(sc, smem);
         __syncthreads();
-        if (active && sc.n_spheres) {
+        if (active && sc.n_prims) {
             const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
             const float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
             const float eps = 2.4e-7f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
             int cur = 0, sp = 0;
-            while (!bvh_step<BLOCK>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, cur, sp, tbest, hit)) {
+            while (!bvh_step<BLOCK, true>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, cur, sp, tbest, hit)) {
             }
         }
     } else {
@@ -646,11 +669,12 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
             __syncthreads();
             closest_hit_tile(s_geo, nn, t0, o, d, a, tbest, hit);
         }
+        closest_hit_rects(sc, o, d, tbest, hit);
     }
     if (!active) return;
     uint32_t n_fetch = 0;
     Rng rng{in_key[2 * i], in_key[2 * i + 1], depth_counter_base(depth)};
-    Bounce bo = shade(sc, PerlinTables{sc.perlin_vec, sc.perlin_perm}, o, d, hit, tbest, rng, n_fetch);
+    Bounce bo = shade<true>(sc, PerlinTables{sc.perlin_vec, sc.perlin_perm}, o, d, hit, tbest, rng, n_fetch);
     out_hit[i] = hit;
     out_t[i] = hit >= 0 ? tbest : 0.0f;
     out_rad[3 * i] = bo.radiance.x, out_rad[3 * i + 1] = bo.radiance.y, out_rad[3 * i + 2] = bo.radiance.z;

@@ -1,8 +1,8 @@
 // demo_scene.cpp — host-side mirror of the reference scene builders that feed the accelerated
 // path (demo_scene.rs:37-86 sphere_scene, demo_scene.rs:229-244 test_sphere) plus the two
 // build-authored scenes BASELINE.json configs 4 and 5 call for.  The other three reference
-// scenes (simple_light_scene, cornell_box, final_scene) need rect/box/medium primitives and are
-// outside the accelerated path.
+// scenes: simple_light_scene (spheres + an XYRect) is mirrored below; cornell_box and final_scene need
+// instance transforms and ConstantMedium, which are not on the accelerated path yet.
 #include "rtow.hpp"
 
 #include <cstdio>
@@ -105,6 +105,22 @@ std::pair<HitableList, Camera> test_sphere(float aspect_ratio) {
     };
     Camera cam = Camera::new_(vec3a(0.0f, 0.0f, 0.0f), vec3a(0.0f, 0.0f, -1.0f), vec3a(0.0f, 1.0f, 0.0f), 90.0f, aspect_ratio);
     return {world, cam};
+}
+
+// demo_scene.rs:88-110 — Perlin ground and sphere lit by an emissive sphere and an emissive XYRect, black sky.
+std::pair<HitableList, Camera> simple_light_scene(float aspect_ratio) {
+    SKY_COLOR_set(SkyFn::black_sky); // :89
+    auto perlin = PerlinTex::new_(4.0f);
+    auto mat_perlin = std::make_shared<Diffuse>(perlin);
+    auto material_1 = std::make_shared<Emission>(std::make_shared<ConstantTex>(vec3a(4.0f, 4.0f, 4.0f)));
+    HitableList world = {
+        std::make_shared<Sphere>(vec3a(1.0f, -1000.0f, -1.0f), 1000.0f, mat_perlin, "Ground"),
+        std::make_shared<Sphere>(vec3a(0.0f, 2.0f, 0.0f), 2.0f, mat_perlin, "Sphere_1"),
+        std::make_shared<Sphere>(vec3a(0.0f, 6.5f, 0.0f), 2.0f, material_1, "Sphere_2"),
+        std::make_shared<XYRect>(vec3a(3.0f, 1.0f, -2.0f), vec3a(5.0f, 3.0f, -2.0f), material_1),
+    };
+    Camera cam = Camera::new_(vec3a(26.0f, 3.0f, 6.0f), vec3a(0.0f, 0.0f, 0.0f), vec3a(0.0f, 1.0f, 0.0f), 20.0f, aspect_ratio);
+    return build_bvh(world, cam); // :109
 }
 
 // BASELINE.json config 4: earthmap-textured sphere under the newport_loft environment sky.

@@ -82,6 +82,7 @@ int rth_scene_build(const char* name, float aspect_ratio, RthScene** out) {
         SceneFn fn = nullptr;
         if (n == "sphere_scene") fn = sphere_scene;
         else if (n == "test_sphere") fn = test_sphere;
+        else if (n == "simple_light_scene") fn = simple_light_scene;
         else if (n == "earth_env_scene") fn = earth_env_scene;
         else if (n == "pbr_sweep_scene") fn = pbr_sweep_scene;
         else throw std::runtime_error("rth_scene_build: unknown scene '" + n + "'");
@@ -164,6 +165,29 @@ uint32_t rth_sphere(RthScene* s, const float c[3], float r, uint32_t material, c
     return guarded_handle([&]() -> uint32_t {
         if (material >= s->materials.size()) throw std::runtime_error("rth_sphere: bad material handle");
         s->world.push_back(std::make_shared<Sphere>(v(c), r, s->materials[material], name ? name : ""));
+        return (uint32_t)s->world.size() - 1;
+    });
+}
+
+uint32_t rth_rect(RthScene* s, uint32_t axis, const float mn[3], const float mx[3], uint32_t material) {
+    return guarded_handle([&]() -> uint32_t {
+        if (material >= s->materials.size()) throw std::runtime_error("rth_rect: bad material handle");
+        HitablePtr r;
+        switch (axis) {
+        case RT_RECT_XY: r = std::make_shared<XYRect>(v(mn), v(mx), s->materials[material]); break;
+        case RT_RECT_XZ: r = std::make_shared<XZRect>(v(mn), v(mx), s->materials[material]); break;
+        case RT_RECT_YZ: r = std::make_shared<YZRect>(v(mn), v(mx), s->materials[material]); break;
+        default: throw std::runtime_error("rth_rect: unknown axis");
+        }
+        s->world.push_back(r);
+        return (uint32_t)s->world.size() - 1;
+    });
+}
+
+uint32_t rth_gbox(RthScene* s, const float mn[3], const float mx[3], uint32_t material) {
+    return guarded_handle([&]() -> uint32_t {
+        if (material >= s->materials.size()) throw std::runtime_error("rth_gbox: bad material handle");
+        s->world.push_back(GBox::new_(v(mn), v(mx), s->materials[material]));
         return (uint32_t)s->world.size() - 1;
     });
 }

@@ -3,6 +3,7 @@
 //
 //   Camera::new_(lookfrom, lookat, vup, vfov_deg, aspect)      camera.rs:14-39
 //   Sphere{c, r, mat, name}                                    hitable.rs:57-62
+//   XYRect/XZRect/YZRect{min, max, mat}, GBox::new_(min,max,mat)  hitable.rs:244-402
 //   HitableList = vector<shared_ptr<Hitable>>                  hitable.rs:114
 //   BvhNode::new_(objects, start, end)                         hitable.rs:177-221
 //   Emission{emit} Diffuse{albedo} Lambert{albedo} Metal{albedo,fuzz} Dielectric{ior}
@@ -148,6 +149,11 @@ class FlatSceneBuilder {
         mat_tex0.push_back(t0), mat_tex1.push_back(t1);
         return (uint32_t)mat_type.size() - 1;
     }
+    void push_rect(uint8_t axis, Vec3A mn, Vec3A mx, uint32_t mat) {
+        rect_axis.push_back(axis);
+        push3(rect_min, mn), push3(rect_max, mx);
+        rect_mat.push_back(mat);
+    }
     void push_sphere(Vec3A c, float r, uint32_t mat, const std::string& name) {
         sph_cx.push_back(c.x), sph_cy.push_back(c.y), sph_cz.push_back(c.z), sph_r.push_back(r), sph_mat.push_back(mat);
         sph_name.push_back(name);
@@ -158,6 +164,8 @@ class FlatSceneBuilder {
         s.n_spheres = (uint32_t)sph_r.size();
         s.sph_cx = sph_cx.data(), s.sph_cy = sph_cy.data(), s.sph_cz = sph_cz.data(), s.sph_r = sph_r.data();
         s.sph_mat = sph_mat.data();
+        s.n_rects = (uint32_t)rect_axis.size();
+        s.rect_axis = rect_axis.data(), s.rect_min = rect_min.data(), s.rect_max = rect_max.data(), s.rect_mat = rect_mat.data();
         s.n_materials = (uint32_t)mat_type.size();
         s.mat_type = mat_type.data(), s.mat_color = mat_color.data();
         s.mat_p0 = mat_p0.data(), s.mat_p1 = mat_p1.data(), s.mat_p2 = mat_p2.data(), s.mat_p3 = mat_p3.data();
@@ -177,6 +185,9 @@ class FlatSceneBuilder {
     std::vector<float> sph_cx, sph_cy, sph_cz, sph_r;
     std::vector<uint32_t> sph_mat;
     std::vector<std::string> sph_name;
+    std::vector<uint8_t> rect_axis;
+    std::vector<float> rect_min, rect_max;
+    std::vector<uint32_t> rect_mat;
     std::vector<uint8_t> mat_type;
     std::vector<float> mat_color, mat_p0, mat_p1, mat_p2, mat_p3;
     std::vector<uint32_t> mat_tex0, mat_tex1;
@@ -429,6 +440,44 @@ struct Sphere : Hitable { // hitable.rs:57-62
     std::string memo() const override { return name; }
 };
 
+// hitable.rs:244-362 — axis-aligned rectangles.  The plane coordinate is min[axis] (max[axis] is ignored by hit()).
+#define RTOW_RECT(Name, AXIS, MEMO)                                                                      \
+    struct Name : Hitable {                                                                              \
+        Vec3A min, max;                                                                                  \
+        MaterialPtr mat;                                                                                 \
+        Name(Vec3A mn, Vec3A mx, MaterialPtr m) : min(mn), max(mx), mat(std::move(m)) {}                 \
+        void flatten(FlatSceneBuilder& b) const override { b.push_rect(AXIS, min, max, b.intern_material(mat.get())); } \
+        std::string memo() const override { return MEMO; }                                               \
+    }
+RTOW_RECT(XYRect, RT_RECT_XY, "XYRect"); // hitable.rs:244-282
+RTOW_RECT(XZRect, RT_RECT_XZ, "XZRect"); // hitable.rs:284-322
+RTOW_RECT(YZRect, RT_RECT_YZ, "YZRect"); // hitable.rs:324-362
+#undef RTOW_RECT
+
+// hitable.rs:364-402 — six rectangles in the order of GBox::new; hit() is the list walk over them.
+class GBox : public Hitable {
+  public:
+    static std::shared_ptr<GBox> new_(Vec3A min, Vec3A max, MaterialPtr mat) {
+        auto g = std::shared_ptr<GBox>(new GBox());
+        g->sides_ = {
+            std::make_shared<XYRect>(vec3a(min.x, min.y, min.z), vec3a(max.x, max.y, min.z), mat),
+            std::make_shared<XYRect>(vec3a(min.x, min.y, max.z), vec3a(max.x, max.y, max.z), mat),
+            std::make_shared<XZRect>(vec3a(min.x, min.y, min.z), vec3a(max.x, min.y, max.z), mat),
+            std::make_shared<XZRect>(vec3a(min.x, max.y, min.z), vec3a(max.x, max.y, max.z), mat),
+            std::make_shared<YZRect>(vec3a(min.x, min.y, min.z), vec3a(min.x, max.y, max.z), mat),
+            std::make_shared<YZRect>(vec3a(max.x, min.y, min.z), vec3a(max.x, max.y, max.z), mat),
+        };
+        return g;
+    }
+    void flatten(FlatSceneBuilder& b) const override {
+        for (auto& s : sides_) s->flatten(b);
+    }
+    std::string memo() const override { throw std::runtime_error("GBox::memo: todo!() in the reference (hitable.rs:399-401)"); }
+
+  private:
+    HitableList sides_;
+};
+
 // hitable.rs:158-221.  The accelerated path does its own closest-hit search, so the mirror
 // keeps the primitives of [start, end) in construction order and replays only the RNG side
 // effect of the reference constructor (one gen_range(0..3) per node, hitable.rs:182-184).
@@ -522,6 +571,7 @@ inline void flatten_world(const HitableList& world, FlatSceneBuilder& b) {
 using SceneFn = std::pair<HitableList, Camera> (*)(float aspect_ratio);
 std::pair<HitableList, Camera> sphere_scene(float aspect_ratio); // demo_scene.rs:37-86  "random-spheres"
 std::pair<HitableList, Camera> test_sphere(float aspect_ratio);  // demo_scene.rs:229-244
+std::pair<HitableList, Camera> simple_light_scene(float aspect_ratio); // demo_scene.rs:88-110 (spheres + XYRect light)
 // Build-authored scenes from reference constructors (BASELINE.json configs 4 and 5; the
 // reference ships no scene for them).
 std::pair<HitableList, Camera> earth_env_scene(float aspect_ratio);

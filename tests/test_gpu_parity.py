@@ -52,7 +52,7 @@ def test_bounce_sphere_scene_all_depth_blocks(rt, orc, renderer):
 
 
 def test_bounce_pbr_and_env_scenes(rt, orc, renderer):
-    for name in ("pbr_sweep_scene", "earth_env_scene", "test_sphere"):
+    for name in ("pbr_sweep_scene", "earth_env_scene", "test_sphere", "simple_light_scene"):
         scene = rt.Scene.build(name, 16 / 9)
         _check_bounce(rt, orc, renderer, scene, n=30000, seed=7)
 
@@ -207,7 +207,8 @@ def test_render_sharding_is_bit_invariant(rt, renderer):
         assert rays == st.n_rays
 
 
-@pytest.mark.parametrize("name,spp,depth", [("test_sphere", 16, 50), ("earth_env_scene", 8, 12), ("pbr_sweep_scene", 8, 6)])
+@pytest.mark.parametrize("name,spp,depth", [("test_sphere", 16, 50), ("earth_env_scene", 8, 12), ("pbr_sweep_scene", 8, 6),
+                                            ("simple_light_scene", 16, 50)])
 def test_render_other_scenes(rt, orc, renderer, name, spp, depth):
     scene = rt.Scene.build(name, 2.0)
     renderer.upload(scene)
@@ -355,3 +356,78 @@ def test_russian_roulette_opt_in(rt, orc, renderer):
     assert st.n_rays < 0.9 * sp.n_rays
     # unbiased: compare LINEAR means (the gamma/clamp of the display transform is not linear in the noise)
     assert abs(img.mean() - plain.mean()) / plain.mean() < 0.01
+
+
+def _box_room(rt, env=None):
+    """Cornell-box geometry from the reference constructors that are on the accelerated path: the five walls and
+    the light of demo_scene.rs:131-136, two axis-aligned GBox (the reference rotates/translates them and fills
+    them with smoke: instance transforms and ConstantMedium are not accelerated yet), a glass and a metal sphere."""
+    s = rt.Scene.new()
+    f = rt._ffi
+    red = s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.65, 0.05, 0.05)))
+    white = s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.73, 0.73, 0.73)))
+    green = s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.12, 0.45, 0.15)))
+    light = s.material(f.MAT_EMISSION, tex0=s.constant_tex((7, 7, 7)))
+    earth = s.material(f.MAT_LAMBERT, tex0=s.image_tex("res/earthmap.jpg"))
+    s.rect(f.RECT_XZ, (113, 554, 127), (443, 554, 432), light)
+    s.rect(f.RECT_XY, (0, 0, 555), (555, 555, 555), earth)   # back wall carries the image texture: rect uv
+    s.rect(f.RECT_XZ, (0, 0, 0), (555, 0, 555), white)
+    s.rect(f.RECT_XZ, (0, 555, 0), (555, 555, 555), white)
+    s.rect(f.RECT_YZ, (0, 0, 0), (0, 555, 555), red)
+    s.rect(f.RECT_YZ, (555, 0, 0), (555, 555, 555), green)
+    s.gbox((265, 0, 295), (430, 330, 460), white)
+    s.gbox((130, 0, 65), (295, 165, 230), s.material(f.MAT_OREN_NAYAR, tex0=s.checker_tex((0.2, 0.3, 0.1), (0.9, 0.9, 0.9)), p=(0.5,)))
+    s.sphere((190, 230, 150), 60.0, s.material(f.MAT_DIELECTRIC, p=(1.5,)), "glass")
+    s.sphere((400, 80, 120), 80.0, s.material(f.MAT_METAL, color=(0.8, 0.85, 0.9), p=(0.05,)), "metal")
+    s.set_sky(f.SKY_BLACK)
+    s.set_camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40, 1.0)
+    return s.finish()
+
+
+def test_rectangles_and_boxes(rt, orc, renderer):
+    """hitable.rs:244-402 on the GPU: XY/XZ/YZ rectangles and GBox sides in the LDS BVH and in the list walk,
+    rect uv for image textures, every result equal to the oracle's."""
+    scene = _box_room(rt)
+    assert scene.flat.n_rects == 18 and scene.flat.n_spheres == 2
+    renderer.upload(scene)
+    rng = np.random.default_rng(5)
+    n = 30000
+    o = rng.uniform(5, 550, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 10] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n // 10)] * rng.choice([-1, 1], (n // 10, 1)).astype(np.float32)
+    ln = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]).astype(np.float32)
+    d = (d * (np.float32(1) / ln)[:, None]).astype(np.float32)
+    keys = rng.integers(0, 2**32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+    g = renderer.debug_bounce(o, d, keys)
+    b = renderer.debug_bounce(o, d, keys, flags=rt._ffi.FLAG_BRUTE_FORCE)
+    c = orc.debug_bounce(scene.flat_ptr, o, d, keys, accel=orc.ACCEL_LIST)
+    for other in (b, c):
+        assert np.array_equal(g["hit"], other["hit"]) and np.array_equal(g["t"].view(np.uint32), other["t"].view(np.uint32))
+        assert np.array_equal(g["alive"], other["alive"])
+        assert np.array_equal(g["o"].view(np.uint32), other["o"].view(np.uint32))
+        assert np.array_equal(g["d"].view(np.uint32), other["d"].view(np.uint32))
+    assert np.allclose(g["attenuation"], c["attenuation"], rtol=2e-5, atol=1e-6) and np.allclose(g["radiance"], c["radiance"], rtol=2e-5, atol=1e-6)
+    assert (g["hit"] >= 2).mean() > 0.8  # inside the room nearly every ray ends on a rectangle
+    p = rt.make_params(200, 200, 16, max_depth=50)
+    img, _, st = renderer.render(scene.camera, p)
+    # the GPU search returns HitableList::hit's result, so the list-walk oracle is the exact reference
+    ref, _, so = _oracle(orc, scene, p, accel=orc.ACCEL_LIST)
+    assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
+    assert st.n_texture_fetches == so.n_texture_fetches and st.n_texture_fetches > 0
+    assert rmse_display(img, ref) <= RMSE_TOL
+    # the reference's own BvhNode culls with UNPADDED boxes (`t_max <= t_min` rejects, math.rs:109): a hit within an
+    # ulp of a rectangle's edge passes XYRect::hit but not the box around it, ~1e-6 of the rays; those paths differ
+    bv, _, sb = _oracle(orc, scene, p, accel=orc.ACCEL_BVH)
+    assert abs(int(sb.n_rays) - int(st.n_rays)) / st.n_rays < 1e-4
+    assert (np.abs(display(img) - display(bv)).max(axis=2) > 1e-3).mean() < 1e-3
+    p.flags = rt._ffi.FLAG_BRUTE_FORCE
+    img2, _, st2 = renderer.render(scene.camera, p)
+    assert np.array_equal(img.view(np.uint32), img2.view(np.uint32)) and st2.n_rays == st.n_rays
+    # DisneyMetal on a rectangle would read the reference's stale HitRecord.tang: refused
+    bad = rt.Scene.new()
+    m = bad.material(rt._ffi.MAT_DISNEY_METAL, tex0=bad.constant_tex((1, 1, 1)), p=(0.3, 0.5, 0.0))
+    bad.rect(rt._ffi.RECT_XY, (0, 0, 0), (1, 1, 0), m)
+    bad.set_camera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40, 1.0)
+    bad.finish()
+    with pytest.raises(rt.RtError, match="stale"):
+        renderer.upload(bad)

@@ -102,3 +102,21 @@ def test_piecewise_construction_and_errors(rt):
         s2.image_tex("res/does_not_exist.jpg")  # image::open(..).unwrap() panics in the reference
     with pytest.raises(rt.RtError):
         s2.finish()  # no camera
+
+
+def test_simple_light_scene_and_boxes(rt):
+    s = rt.Scene.build("simple_light_scene", 16 / 9)  # demo_scene.rs:88-110
+    a = s.arrays()
+    assert s.flat.n_spheres == 3 and s.flat.n_rects == 1 and s.flat.sky_type == rt._ffi.SKY_BLACK
+    assert a["rect_axis"].tolist() == [rt._ffi.RECT_XY] and a["rect_min"].tolist() == [3, 1, -2] and a["rect_max"].tolist() == [5, 3, -2]
+    # the emissive material is shared by Sphere_2 and the rect; the Perlin material by Ground and Sphere_1
+    assert a["sph_mat"].tolist() == [0, 0, 1] and a["rect_mat"].tolist() == [1]
+    assert a["mat_type"].tolist() == [rt._ffi.MAT_DIFFUSE, rt._ffi.MAT_EMISSION]
+    b = rt.Scene.new()
+    m = b.material(rt._ffi.MAT_DIFFUSE, tex0=b.constant_tex((0.5, 0.5, 0.5)))
+    b.gbox((0, 0, 0), (1, 2, 3), m)
+    b.set_camera((5, 5, 5), (0, 0, 0), (0, 1, 0), 40, 1.0)
+    b.finish()
+    a = b.arrays()  # GBox::new order: XY(min.z), XY(max.z), XZ(min.y), XZ(max.y), YZ(min.x), YZ(max.x)
+    assert a["rect_axis"].tolist() == [2, 2, 1, 1, 0, 0]
+    assert a["rect_min"].reshape(6, 3)[[0, 1, 2, 3, 4, 5], [2, 2, 1, 1, 0, 0]].tolist() == [0, 3, 0, 2, 0, 1]

@@ -134,3 +134,15 @@ def test_russian_roulette_is_unbiased_and_shortens_paths(rt, orc, cfg1):
     # the two estimator orders agree with the flag as well
     c, _, sc = orc.render(scene.flat_ptr, scene.camera, p1, orc.options(estimator=orc.EST_ITERATIVE))
     assert sc.n_rays == sb.n_rays and rmse_display(b, c) < 1e-6
+
+
+def test_simple_light_scene_oracle(rt, orc):
+    """demo_scene.rs:88-110: black sky, all light comes from the emissive sphere and the emissive XYRect."""
+    scene = rt.Scene.build("simple_light_scene", 2.0)
+    p = rt.make_params(160, 80, 16, max_depth=20)
+    a, _, sa = orc.render(scene.flat_ptr, scene.camera, p, orc.options(accel=orc.ACCEL_LIST))
+    b, _, sb = orc.render(scene.flat_ptr, scene.camera, p, orc.options(accel=orc.ACCEL_BVH))
+    assert sa.n_rays == sb.n_rays and np.array_equal(a, b)
+    assert a.max() <= 4.0 + 1e-5 and a.max() == 4.0 and a.min() == 0.0  # emitters are (4,4,4), seen directly somewhere
+    c, _, sc = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_STREAM))
+    assert abs(a.mean() - c.mean()) / a.mean() < 0.05

@@ -154,3 +154,26 @@ def test_counter_rng_is_a_function_of_key_and_counter(orc):
     assert len(set(draws.tolist())) == 4096
     u = (draws >> 8).astype(np.float64) / 16777216.0
     assert abs(u.mean() - 0.5) < 0.02 and abs(u.var() - 1 / 12) < 0.01
+
+
+def test_rect_hit_known_answers(orc):
+    """hitable.rs:244-362: t = (k - o)/d on the constant axis, bounds inclusive, uv = (p - min)/(max - min)."""
+    lib = orc.load()
+    out = np.zeros(10, np.float32)
+    mn, mx = fa([3, 1, -2]), fa([5, 3, -2])  # the XYRect of simple_light_scene (demo_scene.rs:100)
+    assert lib.orc_rect_hit(2, fp(mn), fp(mx), fp(fa([4, 2, 0])), fp(fa([0, 0, -1])), 1e-3, 3.4e38, fp(out)) == 1
+    assert out[0] == 2.0 and out[1:4].tolist() == [4, 2, -2] and out[4:7].tolist() == [0, 0, 1] and out[7] == 1.0
+    assert out[8:10].tolist() == [0.5, 0.5]
+    # from behind: same plane, flipped normal, front_face false
+    assert lib.orc_rect_hit(2, fp(mn), fp(mx), fp(fa([4, 2, -4])), fp(fa([0, 0, 1])), 1e-3, 3.4e38, fp(out)) == 1
+    assert out[4:7].tolist() == [0, 0, -1] and out[7] == 0.0
+    # the edge is inside (`p.x < min.x || p.x > max.x`), just outside is not; t_max is inclusive (`t > t_max`)
+    assert lib.orc_rect_hit(2, fp(mn), fp(mx), fp(fa([5, 3, 0])), fp(fa([0, 0, -1])), 1e-3, 3.4e38, fp(out)) == 1
+    assert lib.orc_rect_hit(2, fp(mn), fp(mx), fp(fa([5.001, 3, 0])), fp(fa([0, 0, -1])), 1e-3, 3.4e38, fp(out)) == 0
+    assert lib.orc_rect_hit(2, fp(mn), fp(mx), fp(fa([4, 2, 0])), fp(fa([0, 0, -1])), 1e-3, 2.0, fp(out)) == 1
+    assert lib.orc_rect_hit(2, fp(mn), fp(mx), fp(fa([4, 2, 0])), fp(fa([0, 0, -1])), 1e-3, 1.999, fp(out)) == 0
+    # XZ (axis 1): uv = (x, z); YZ (axis 0): uv = (y, z)
+    assert lib.orc_rect_hit(1, fp(fa([0, 5, 0])), fp(fa([4, 5, 2])), fp(fa([1, 9, 0.5])), fp(fa([0, -1, 0])), 1e-3, 3.4e38, fp(out)) == 1
+    assert out[0] == 4.0 and out[8:10].tolist() == [0.25, 0.25] and out[4:7].tolist() == [0, 1, 0]
+    assert lib.orc_rect_hit(0, fp(fa([7, 0, 0])), fp(fa([7, 4, 2])), fp(fa([0, 1, 1])), fp(fa([1, 0, 0])), 1e-3, 3.4e38, fp(out)) == 1
+    assert out[0] == 7.0 and out[8:10].tolist() == [0.25, 0.5] and out[4:7].tolist() == [-1, 0, 0]
