@@ -431,3 +431,38 @@ def test_rectangles_and_boxes(rt, orc, renderer):
     bad.finish()
     with pytest.raises(rt.RtError, match="stale"):
         renderer.upload(bad)
+
+
+def test_repeated_renders_reuploads_and_contexts(rt):
+    """Buffers are reused across calls, scenes can be replaced, two contexts coexist, and nothing leaks."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself is linked against
+
+    def free_bytes():
+        f, tot = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(tot)) == 0
+        return f.value
+
+    a, b = rt.Renderer(0), rt.Renderer(0)
+    free0 = free_bytes()
+    s1, s2 = rt.Scene.build("sphere_scene", 2.0), rt.Scene.build("simple_light_scene", 2.0)
+    a.upload(s1)
+    b.upload(s2)
+    ref1, _, _ = a.render(s1.camera, rt.make_params(96, 48, 4, max_depth=10))
+    ref2, _, _ = b.render(s2.camera, rt.make_params(96, 48, 4, max_depth=10))
+    free_mid = None
+    for it in range(12):
+        nx = 96 if it % 2 == 0 else 64
+        i1, _, _ = a.render(s1.camera, rt.make_params(nx, nx // 2, 4, max_depth=10))
+        i2, _, _ = b.render(s2.camera, rt.make_params(nx, nx // 2, 4, max_depth=10))
+        if nx == 96:
+            assert np.array_equal(i1, ref1) and np.array_equal(i2, ref2)
+        a.upload(s2 if it % 3 == 2 else s1)  # replace the scene, then put it back
+        a.upload(s1)
+        if it == 3:
+            free_mid = free_bytes()
+    assert abs(free_bytes() - free_mid) < (8 << 20)  # steady state: no growth per call
+    a.close()
+    b.close()
+    assert free0 - free_bytes() < (64 << 20)  # everything the two contexts allocated is released
