@@ -56,6 +56,10 @@ uint32_t rth_sphere(RthScene* s, const float c[3], float r, uint32_t material, c
 /* hitable.rs:244-362 XYRect/XZRect/YZRect { min, max, mat } (axis = RtRectAxis) and hitable.rs:364-383 GBox::new */
 uint32_t rth_rect(RthScene* s, uint32_t axis, const float mn[3], const float mx[3], uint32_t material);
 uint32_t rth_gbox(RthScene* s, const float mn[3], const float mx[3], uint32_t material);
+/* hitable.rs:404-520: wrap the world entry `hitable` in Translate { offset, ptr } / RotateY::new(ptr, angle);
+ * the handle stays valid and now denotes the wrapper (wrappers nest, outermost applied last) */
+uint32_t rth_translate(RthScene* s, uint32_t hitable, const float offset[3]);
+uint32_t rth_rotate_y(RthScene* s, uint32_t hitable, float angle_degrees);
 /* sky = RtSkyType; env_path only for RT_SKY_ENV */
 int rth_set_sky(RthScene* s, uint32_t sky, const char* env_path);
 int rth_set_camera(RthScene* s, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2u
+#define RT_ABI_VERSION 3u
 
 /* error codes */
 #define RT_OK 0
@@ -84,14 +84,26 @@ enum RtRectAxis {
     RT_RECT_XY = 2  /* XYRect hitable.rs:244-282  z = min.z, normal +Z, uv = (x, y) */
 };
 
+/* Instance transforms (hitable.rs:404-520).  A primitive below `Translate { offset, ptr }` /
+ * `RotateY::new(ptr, angle)` wrappers carries the index of its INNERMOST wrapper; xf_parent links
+ * each wrapper to the next one outwards (RT_NO_XFORM at the top).  hit() applies the chain to the
+ * ray from the outside in and fixes the HitRecord from the inside out, exactly like the nested
+ * trait objects do (including RotateY's face-normal quirk, hitable.rs:505). */
+enum RtXformType {
+    RT_XF_TRANSLATE = 0, /* param = offset.x, offset.y, offset.z, 0   hitable.rs:404-418 */
+    RT_XF_ROTATE_Y = 1   /* param = sin_theta, cos_theta, angle_degrees, 0   hitable.rs:438-510 */
+};
+#define RT_NO_XFORM 0xFFFFFFFFu
+#define RT_MAX_XFORM_CHAIN 4u /* nesting depth the kernels support */
+
 #define RT_NO_TEX 0xFFFFFFFFu
 #define RT_PERLIN_POINTS 256u /* texture.rs:51 */
 
 /*
  * Flattened structure-of-arrays scene.  Replaces `Vec<Arc<dyn Hitable>>` + the trait
  * objects behind it (hitable.rs:57-62, material.rs, pbr.rs, texture.rs).  Spheres (SURVEY.md
- * §8(a) a4) and axis-aligned rectangles / boxes (§8(f) rank 1) are on the accelerated path;
- * instance transforms (Translate, RotateY) and ConstantMedium are not yet.
+ * §8(a) a4), axis-aligned rectangles / boxes and the Translate / RotateY instance wrappers
+ * (§8(f) rank 1) are on the accelerated path; ConstantMedium is not yet.
  */
 typedef struct RtFlatScene {
     /* spheres: hitable.rs:57-62 `Sphere { c, r, mat, name }` in world-list order */
@@ -111,6 +123,14 @@ typedef struct RtFlatScene {
     const float* rect_min;     /* [3*n_rects] `min` as written in the scene */
     const float* rect_max;     /* [3*n_rects] `max` */
     const uint32_t* rect_mat;  /* [n_rects] */
+
+    /* instance transforms */
+    uint32_t n_xforms;
+    const uint8_t* xf_type;     /* [n_xforms] RtXformType */
+    const float* xf_param;      /* [4*n_xforms] */
+    const uint32_t* xf_parent;  /* [n_xforms] next wrapper outwards or RT_NO_XFORM */
+    const uint32_t* sph_xform;  /* [n_spheres] innermost wrapper or RT_NO_XFORM; NULL = none */
+    const uint32_t* rect_xform; /* [n_rects]   likewise */
 
     /* materials */
     uint32_t n_materials;

@@ -505,13 +505,78 @@ inline bool prim_hit(const RtFlatScene& fs, int i, const Ray& r, float t_min, fl
     return i < (int)fs.n_spheres ? sphere_hit(fs, i, r, t_min, t_max, rec) : rect_hit(fs, i - (int)fs.n_spheres, r, t_min, t_max, rec);
 }
 
+/* ---- instance wrappers, hitable.rs:404-520 ------------------------------------------------- */
+inline uint32_t prim_xform(const RtFlatScene& fs, int i) {
+    if (i < (int)fs.n_spheres) return fs.sph_xform ? fs.sph_xform[i] : RT_NO_XFORM;
+    return fs.rect_xform ? fs.rect_xform[i - (int)fs.n_spheres] : RT_NO_XFORM;
+}
+inline Ray xform_ray(const RtFlatScene& fs, uint32_t x, const Ray& r) {
+    const float* q = fs.xf_param + 4 * (size_t)x;
+    if (fs.xf_type[x] == RT_XF_TRANSLATE) return Ray{r.o - v3(q[0], q[1], q[2]), r.d}; /* hitable.rs:411 */
+    const float sin_theta = q[0], cos_theta = q[1]; /* hitable.rs:483-492 */
+    V3 oo = r.o, dd = r.d;
+    oo.x = cos_theta * r.o.x - sin_theta * r.o.z;
+    oo.z = sin_theta * r.o.x + cos_theta * r.o.z;
+    dd.x = cos_theta * r.d.x - sin_theta * r.d.z;
+    dd.z = sin_theta * r.d.x + cos_theta * r.d.z;
+    return Ray{oo, dd};
+}
+/* `inner` is the ray the wrapper handed to its child (moved_r / rot_r) */
+inline void xform_fix_record(const RtFlatScene& fs, uint32_t x, const Ray& inner, HitRecord& rec) {
+    const float* q = fs.xf_param + 4 * (size_t)x;
+    if (fs.xf_type[x] == RT_XF_TRANSLATE) { /* hitable.rs:413: only rec.p moves */
+        rec.p = rec.p + v3(q[0], q[1], q[2]);
+        return;
+    }
+    const float sin_theta = q[0], cos_theta = q[1]; /* hitable.rs:495-505 */
+    V3 p = rec.p, n = rec.norm;
+    p.x = cos_theta * rec.p.x + sin_theta * rec.p.z;
+    p.z = -sin_theta * rec.p.x + cos_theta * rec.p.z;
+    n.x = cos_theta * rec.norm.x + sin_theta * rec.norm.z;
+    n.z = -sin_theta * rec.norm.x + cos_theta * rec.norm.z;
+    rec.p = p;
+    set_face_normal(rec, inner, n); /* quirk kept: the object-space ray against the world-space normal */
+}
+/* a primitive below its chain of wrappers: ray outside-in, record inside-out */
+inline bool prim_hit_x(const RtFlatScene& fs, int i, const Ray& r, float t_min, float t_max, HitRecord& rec) {
+    uint32_t chain[RT_MAX_XFORM_CHAIN];
+    int n = 0;
+    for (uint32_t x = prim_xform(fs, i); x != RT_NO_XFORM && n < (int)RT_MAX_XFORM_CHAIN; x = fs.xf_parent[x]) chain[n++] = x;
+    if (n == 0) return prim_hit(fs, i, r, t_min, t_max, rec);
+    Ray rays[RT_MAX_XFORM_CHAIN + 1];
+    rays[n] = r;
+    for (int k = n - 1; k >= 0; --k) rays[k] = xform_ray(fs, chain[k], rays[k + 1]);
+    if (!prim_hit(fs, i, rays[0], t_min, t_max, rec)) return false;
+    for (int k = 0; k < n; ++k) xform_fix_record(fs, chain[k], rays[k], rec);
+    return true;
+}
+/* world-space bounds of a wrapped primitive: corners through the wrappers, as RotateY::new does (hitable.rs:455-473) */
+inline AABB xform_bbox(const RtFlatScene& fs, uint32_t x, const AABB& b) {
+    const float* q = fs.xf_param + 4 * (size_t)x;
+    if (fs.xf_type[x] == RT_XF_TRANSLATE) { /* hitable.rs:420-431 */
+        V3 off = v3(q[0], q[1], q[2]);
+        return AABB{b.mn + off, b.mx + off};
+    }
+    const float sin_theta = q[0], cos_theta = q[1];
+    V3 mn = splat(INFINITY), mx = splat(-INFINITY);
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int k = 0; k < 2; ++k) {
+                float x0 = i == 0 ? b.mn.x : b.mx.x, y0 = j == 0 ? b.mn.y : b.mx.y, z0 = k == 0 ? b.mn.z : b.mx.z;
+                float nx = cos_theta * x0 + sin_theta * z0, nz = -sin_theta * x0 + cos_theta * z0;
+                mn = v3(std::fmin(mn.x, nx), std::fmin(mn.y, y0), std::fmin(mn.z, nz));
+                mx = v3(std::fmax(mx.x, nx), std::fmax(mx.y, y0), std::fmax(mx.z, nz));
+            }
+    return AABB{mn, mx};
+}
+
 /* hitable.rs:117-132 HitableList::hit over the flat primitive list (world order). */
 inline bool list_hit(const RtFlatScene& fs, const Ray& r, float t_min, float t_max, HitRecord& rec) {
     HitRecord temp_rec;
     float closest_so_far = t_max;
     bool hit_anything = false;
     for (uint32_t i = 0; i < fs.n_spheres + fs.n_rects; ++i) {
-        if (prim_hit(fs, (int)i, r, t_min, closest_so_far, temp_rec)) {
+        if (prim_hit_x(fs, (int)i, r, t_min, closest_so_far, temp_rec)) {
             hit_anything = true;
             closest_so_far = temp_rec.t;
         }
@@ -529,11 +594,17 @@ struct Bvh {
     std::vector<BvhNode> nodes;
     int root = -1;
 };
-inline AABB sphere_bbox(const RtFlatScene& fs, int idx) { /* hitable.rs:104-108 */
-    if (idx >= (int)fs.n_spheres) return rect_bbox(fs, idx - (int)fs.n_spheres);
-    V3 c = v3(fs.sph_cx[idx], fs.sph_cy[idx], fs.sph_cz[idx]);
-    float r = fs.sph_r[idx];
-    return AABB{c - r, c + r};
+inline AABB sphere_bbox(const RtFlatScene& fs, int idx) { /* hitable.rs:104-108; wrapped primitives: world bounds */
+    AABB b;
+    if (idx >= (int)fs.n_spheres) {
+        b = rect_bbox(fs, idx - (int)fs.n_spheres);
+    } else {
+        V3 c = v3(fs.sph_cx[idx], fs.sph_cy[idx], fs.sph_cz[idx]);
+        float r = fs.sph_r[idx];
+        b = AABB{c - r, c + r};
+    }
+    for (uint32_t x = prim_xform(fs, idx); x != RT_NO_XFORM; x = fs.xf_parent[x]) b = xform_bbox(fs, x, b);
+    return b;
 }
 /* f32::total_cmp key */
 inline int32_t total_key(float f) {
@@ -574,7 +645,7 @@ int bvh_build(const RtFlatScene& fs, Bvh& bvh, std::vector<int>& objects, size_t
 }
 bool bvh_hit(const RtFlatScene& fs, const Bvh& bvh, int node, const Ray& r, float t_min, float t_max,
              HitRecord& rec) { /* hitable.rs:232-240 */
-    if (node < 0) return prim_hit(fs, ~node, r, t_min, t_max, rec);
+    if (node < 0) return prim_hit_x(fs, ~node, r, t_min, t_max, rec);
     const BvhNode& n = bvh.nodes[(size_t)node];
     if (!aabb_hit(n.box, r, t_min, t_max)) return false;
     bool hit_left = bvh_hit(fs, bvh, n.left, r, t_min, t_max, rec);
@@ -1054,6 +1125,8 @@ static int validate_scene(const RtFlatScene* fs) {
         if (fs->sph_mat[i] >= fs->n_materials) return RT_ERR_INVALID;
     for (uint32_t i = 0; i < fs->n_rects; ++i)
         if (fs->rect_mat[i] >= fs->n_materials || fs->rect_axis[i] > RT_RECT_XY) return RT_ERR_INVALID;
+    for (uint32_t i = 0; i < fs->n_xforms; ++i)
+        if (fs->xf_type[i] > RT_XF_ROTATE_Y || (fs->xf_parent[i] != RT_NO_XFORM && fs->xf_parent[i] >= i)) return RT_ERR_INVALID;
     return RT_OK;
 }
 

@@ -78,6 +78,12 @@ class Scene:
     def gbox(self, mn, mx, material):
         return self._check(self._lib.rth_gbox(self._h, _f3(mn), _f3(mx), material))
 
+    def translate(self, hitable, offset):
+        return self._check(self._lib.rth_translate(self._h, hitable, _f3(offset)))
+
+    def rotate_y(self, hitable, angle_degrees):
+        return self._check(self._lib.rth_rotate_y(self._h, hitable, C.c_float(angle_degrees)))
+
     def set_sky(self, sky, env_path=None):
         if self._lib.rth_set_sky(self._h, sky, env_path.encode() if env_path else None) != 0:
             raise RtError(self._lib.rth_last_error().decode())
@@ -132,6 +138,9 @@ class Scene:
             "sph_mat": arr(fs.sph_mat, ns, np.uint32),
             "rect_axis": arr(fs.rect_axis, fs.n_rects, np.uint8), "rect_min": arr(fs.rect_min, 3 * fs.n_rects, np.float32),
             "rect_max": arr(fs.rect_max, 3 * fs.n_rects, np.float32), "rect_mat": arr(fs.rect_mat, fs.n_rects, np.uint32),
+            "xf_type": arr(fs.xf_type, fs.n_xforms, np.uint8), "xf_param": arr(fs.xf_param, 4 * fs.n_xforms, np.float32),
+            "xf_parent": arr(fs.xf_parent, fs.n_xforms, np.uint32), "sph_xform": arr(fs.sph_xform, ns, np.uint32),
+            "rect_xform": arr(fs.rect_xform, fs.n_rects, np.uint32),
             "mat_type": arr(fs.mat_type, nm, np.uint8), "mat_color": arr(fs.mat_color, 3 * nm, np.float32),
             "mat_p0": arr(fs.mat_p0, nm, np.float32), "mat_p1": arr(fs.mat_p1, nm, np.float32),
             "mat_p2": arr(fs.mat_p2, nm, np.float32), "mat_p3": arr(fs.mat_p3, nm, np.float32),

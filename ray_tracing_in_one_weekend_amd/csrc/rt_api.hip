@@ -211,6 +211,24 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     for (uint32_t i = 0; i < s->n_spheres; ++i)
         if (s->sph_mat[i] >= s->n_materials)
             return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: sphere " + std::to_string(i) + " has material index out of range");
+    if (s->n_xforms && (!s->xf_type || !s->xf_param || !s->xf_parent))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: transform arrays missing");
+    for (uint32_t i = 0; i < s->n_xforms; ++i) {
+        if (s->xf_type[i] > RT_XF_ROTATE_Y) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: unknown transform type");
+        if (s->xf_parent[i] != RT_NO_XFORM && s->xf_parent[i] >= i)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: transform parent must precede its child");
+    }
+    auto chain_ok = [&](uint32_t x) {
+        uint32_t n = 0;
+        for (; x != RT_NO_XFORM; x = s->xf_parent[x]) {
+            if (x >= s->n_xforms || ++n > RT_MAX_XFORM_CHAIN) return false;
+        }
+        return true;
+    };
+    for (uint32_t i = 0; i < s->n_spheres && s->sph_xform; ++i)
+        if (!chain_ok(s->sph_xform[i])) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad sphere transform chain");
+    for (uint32_t i = 0; i < s->n_rects && s->rect_xform; ++i)
+        if (!chain_ok(s->rect_xform[i])) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad rectangle transform chain");
     if (s->n_rects && (!s->rect_axis || !s->rect_min || !s->rect_max || !s->rect_mat))
         return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: rectangle arrays missing");
     for (uint32_t i = 0; i < s->n_rects; ++i) {
@@ -320,6 +338,41 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         for (int k = 0; k < 3; ++k) b.mn[k] = std::min(mn[k], mx[k]), b.mx[k] = std::max(mn[k], mx[k]);
         b.mn[ax] = mn[ax] - 0.0001f, b.mx[ax] = mn[ax] + 0.0001f; // the plane the hit test uses (hitable.rs:253)
     }
+    // instance wrappers: per-primitive innermost wrapper, and world-space bounds through the chain (corners
+    // through every wrapper from the inside out, as RotateY::new does at hitable.rs:455-473)
+    std::vector<uint32_t> pxf(n_prims, RT_NO_XFORM);
+    std::vector<float4> xparam(s->n_xforms);
+    std::vector<uint2> xmeta(s->n_xforms);
+    for (uint32_t i = 0; i < s->n_xforms; ++i) {
+        xparam[i] = make_float4(s->xf_param[4 * i], s->xf_param[4 * i + 1], s->xf_param[4 * i + 2], s->xf_param[4 * i + 3]);
+        xmeta[i] = make_uint2(s->xf_type[i], s->xf_parent[i]);
+    }
+    for (uint32_t i = 0; i < n_prims; ++i) {
+        const uint32_t x0 = i < s->n_spheres ? (s->sph_xform ? s->sph_xform[i] : RT_NO_XFORM)
+                                             : (s->rect_xform ? s->rect_xform[i - s->n_spheres] : RT_NO_XFORM);
+        pxf[i] = x0;
+        for (uint32_t x = x0; x != RT_NO_XFORM; x = s->xf_parent[x]) {
+            PrimBox& b = pboxes[i];
+            const float* q = s->xf_param + 4 * (size_t)x;
+            if (s->xf_type[x] == RT_XF_TRANSLATE) {
+                for (int k = 0; k < 3; ++k) b.mn[k] += q[k], b.mx[k] += q[k];
+            } else {
+                const float sn = q[0], cs = q[1];
+                float mn[3] = {FLT_MAX, b.mn[1], FLT_MAX}, mx[3] = {-FLT_MAX, b.mx[1], -FLT_MAX};
+                for (int ci = 0; ci < 4; ++ci) {
+                    const float x0c = (ci & 1) ? b.mx[0] : b.mn[0], z0c = (ci & 2) ? b.mx[2] : b.mn[2];
+                    const float nx = cs * x0c + sn * z0c, nz = -sn * x0c + cs * z0c;
+                    mn[0] = std::min(mn[0], nx), mx[0] = std::max(mx[0], nx);
+                    mn[2] = std::min(mn[2], nz), mx[2] = std::max(mx[2], nz);
+                }
+                // the rotation itself rounds: widen by a few ulp of the coordinate magnitude
+                for (int k = 0; k < 3; k += 2) {
+                    const float e = 1e-6f * std::max(std::fabs(mn[k]), std::fabs(mx[k]));
+                    b.mn[k] = mn[k] - e, b.mx[k] = mx[k] + e;
+                }
+            }
+        }
+    }
     HostBvh bvh;
     build_prim_bvh(pboxes, RT_BVH_MAX_DEPTH, bvh);
     std::vector<uint8_t> sclass(n_prims);
@@ -346,6 +399,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
     DevScene ds{};
+    ds.n_xforms = s->n_xforms;
     ds.n_rects = s->n_rects;
     ds.n_prims = n_prims;
     ds.n_bvh4_nodes = (uint32_t)bvh4.id.size();
@@ -356,7 +410,8 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     if ((rc = upload(ctx, geo, &ds.sph_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
         (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
-        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, rgeo, &ds.rect_geo)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
+        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, rgeo, &ds.rect_geo)) || (rc = upload(ctx, pxf, &ds.prim_xform)) || (rc = upload(ctx, xparam, &ds.xf_param)) ||
+        (rc = upload(ctx, xmeta, &ds.xf_meta)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
         (rc = upload(ctx, bvh4.p[0], &ds.bvh4_p[0])) || (rc = upload(ctx, bvh4.p[1], &ds.bvh4_p[1])) ||
         (rc = upload(ctx, bvh4.p[2], &ds.bvh4_p[2])) || (rc = upload(ctx, bvh4.p[3], &ds.bvh4_p[3])) ||
         (rc = upload(ctx, bvh4.p[4], &ds.bvh4_p[4])) || (rc = upload(ctx, bvh4.p[5], &ds.bvh4_p[5]))) {
@@ -496,7 +551,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         }
     }
     const IntersectParams ip{nq, cap};
-    const bool rects = ctx->ds.n_rects > 0; // selects the kernel instantiations with the rectangle branches
+    // selects the "general scene" kernel instantiations (rectangles and Translate / RotateY wrappers)
+    const bool rects = ctx->ds.n_rects > 0 || ctx->ds.n_xforms > 0;
     for (uint32_t sl = 0; sl < n_slices; ++sl) {
         const uint32_t s0 = sl * S;
         const uint32_t sc = std::min(S, spp - s0);

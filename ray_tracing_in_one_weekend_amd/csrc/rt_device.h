@@ -174,6 +174,11 @@ struct ImgRec { // 16 B
     uint32_t offset_lo, offset_hi; // offset in texels into the float4 texel pool
 };
 struct DevScene {
+    // instance wrappers (hitable.rs:404-520): xf_param = (offset xyz | sin, cos, angle), xf_meta = (type, parent)
+    uint32_t n_xforms;
+    const float4* xf_param;
+    const uint2* xf_meta;
+    const uint32_t* prim_xform; // [n_prims] innermost wrapper of the primitive or RT_NO_XFORM_DEV
     uint32_t n_rects;   // axis-aligned rectangles; primitive index = n_spheres + rect index
     uint32_t n_prims;   // n_spheres + n_rects
     const float4* rect_geo; // 2 per rect: (k, u0, u1, v0), (v1, axis bits, 0, 0); (u, v) = uv axes of the rect
@@ -414,6 +419,48 @@ __device__ __forceinline__ bool rect_root(float4 g0, float4 g1, V3 o, V3 d, floa
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Instance wrappers Translate / RotateY (hitable.rs:404-520) as a per-primitive chain
+// ---------------------------------------------------------------------------------------------
+#define RT_NO_XFORM_DEV 0xFFFFFFFFu
+#define RT_MAX_CHAIN 4
+struct Chain {
+    uint32_t id[RT_MAX_CHAIN]; // id[0] = innermost wrapper ... id[n-1] = outermost
+    int n;
+};
+__device__ __forceinline__ Chain load_chain(const DevScene& sc, uint32_t xf) {
+    Chain c;
+    c.n = 0;
+#pragma unroll
+    for (int k = 0; k < RT_MAX_CHAIN; ++k) {
+        c.id[k] = xf;
+        if (xf != RT_NO_XFORM_DEV) {
+            ++c.n;
+            xf = sc.xf_meta[xf].y;
+        }
+    }
+    return c;
+}
+// The ray a wrapper hands to its child: Translate moves the origin (hitable.rs:411), RotateY rotates origin
+// and direction (hitable.rs:483-492).
+__device__ __forceinline__ void xform_ray(const DevScene& sc, uint32_t x, V3& o, V3& d) {
+    const float4 q = sc.xf_param[x];
+    if (sc.xf_meta[x].x == 0u) {
+        o = o - v3(q.x, q.y, q.z);
+    } else {
+        const float sin_theta = q.x, cos_theta = q.y;
+        const float ox = cos_theta * o.x - sin_theta * o.z, oz = sin_theta * o.x + cos_theta * o.z;
+        const float dx = cos_theta * d.x - sin_theta * d.z, dz = sin_theta * d.x + cos_theta * d.z;
+        o.x = ox, o.z = oz, d.x = dx, d.z = dz;
+    }
+}
+// world ray -> the ray the primitive itself is tested with (outermost wrapper first)
+__device__ __forceinline__ void chain_to_object(const DevScene& sc, const Chain& c, V3& o, V3& d) {
+#pragma unroll
+    for (int k = RT_MAX_CHAIN - 1; k >= 0; --k)
+        if (k < c.n) xform_ray(sc, c.id[k], o, d);
+}
+
 // Result of one bounce for one ray.
 struct Bounce {
     V3 radiance;    // emitted (hit) or sky (miss) term of this segment, untinted
@@ -442,6 +489,16 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     const float4* rec = sc.sph_rec + 5u * (uint32_t)hit;
     const float4 g = rec[0], r1 = rec[1];
     const bool is_rect = RECTS && (uint32_t)hit >= sc.n_spheres;
+    // RECTS also stands for "general scene": the primitive may sit below Translate / RotateY wrappers.  The
+    // HitRecord is then built from the innermost (object-space) ray and fixed on the way out (hitable.rs:412-414,
+    // 494-506); `ro`/`rd` stay the world ray that scatter() receives (main.rs:48).
+    Chain chain;
+    chain.n = 0;
+    V3 wo = ro, wd = rd; // the world ray
+    if (RECTS) {
+        chain = load_chain(sc, sc.prim_xform[hit]);
+        chain_to_object(sc, chain, ro, rd);
+    }
     V3 p = ro + rd * t;                                 // math.rs:64 Ray::at
     V3 on;
     V2 rect_uv = V2{0.0f, 0.0f};
@@ -457,6 +514,32 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     }
     bool front_face = dot(rd, on) < 0.0f;               // hitable.rs:26
     V3 n = front_face ? on : -on;                       // hitable.rs:27-31
+    if (RECTS && chain.n > 0) {
+        // unwind the wrappers from the inside out
+#pragma unroll
+        for (int k = 0; k < RT_MAX_CHAIN; ++k) {
+            if (k < chain.n) {
+                const uint32_t x = chain.id[k];
+                const float4 q = sc.xf_param[x];
+                if (sc.xf_meta[x].x == 0u) { // Translate: only rec.p moves (hitable.rs:413)
+                    p = p + v3(q.x, q.y, q.z);
+                } else { // RotateY (hitable.rs:495-505)
+                    const float sin_theta = q.x, cos_theta = q.y;
+                    const float px = cos_theta * p.x + sin_theta * p.z, pz = -sin_theta * p.x + cos_theta * p.z;
+                    const float nx = cos_theta * n.x + sin_theta * n.z, nz = -sin_theta * n.x + cos_theta * n.z;
+                    p.x = px, p.z = pz, n.x = nx, n.z = nz;
+                    // set_face_normal(&rot_r, n): rot_r.d = the world direction through the wrappers k..n-1
+                    V3 dk = wd, ok = wo;
+#pragma unroll
+                    for (int j = RT_MAX_CHAIN - 1; j >= 0; --j)
+                        if (j < chain.n && j >= k) xform_ray(sc, chain.id[j], ok, dk);
+                    front_face = dot(dk, n) < 0.0f;
+                    n = front_face ? n : -n;
+                }
+            }
+        }
+        ro = wo, rd = wd; // materials see the world ray
+    }
     // the material fields are fetched where a branch needs them (keeps the live set small)
     struct {
         uint32_t type, tex1;

@@ -135,9 +135,25 @@ __device__ __forceinline__ void closest_hit_tile(const float4* s_geo, uint32_t n
 __device__ __forceinline__ void closest_hit_rects(const DevScene& sc, V3 o, V3 d, float& tbest, int& hit) {
     for (uint32_t r = 0; r < sc.n_rects; ++r) {
         float th;
-        if (rect_root(sc.rect_geo[2u * r], sc.rect_geo[2u * r + 1u], o, d, 1e-3f, tbest, th)) {
+        V3 po = o, pd = d;
+        const uint32_t xf = sc.prim_xform[sc.n_spheres + r];
+        if (xf != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, xf), po, pd);
+        if (rect_root(sc.rect_geo[2u * r], sc.rect_geo[2u * r + 1u], po, pd, 1e-3f, tbest, th)) {
             tbest = th;
             hit = (int)(sc.n_spheres + r);
+        }
+    }
+}
+// List walk over spheres of a scene with wrappers (read from HBM; the LDS tile loop assumes none).
+__device__ __forceinline__ void closest_hit_spheres_general(const DevScene& sc, V3 o, V3 d, float& tbest, int& hit) {
+    for (uint32_t s = 0; s < sc.n_spheres; ++s) {
+        float th;
+        V3 po = o, pd = d;
+        const uint32_t xf = sc.prim_xform[s];
+        if (xf != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, xf), po, pd);
+        if (sphere_root(sc.sph_geo[s], po, pd, length_squared(pd), 1e-3f, tbest, th)) {
+            tbest = th;
+            hit = (int)s;
         }
     }
 }
@@ -164,6 +180,7 @@ struct BvhLds {
     const int4* id;
     const float4* geo;     // spheres (1 float4 each), then rectangles (2 float4 each)
     uint32_t n_spheres;
+    const DevScene* sc;    // wrapper tables of general scenes (HBM)
     unsigned short* stack; // this lane's column: stack[level * BLOCK]
 };
 
@@ -186,6 +203,7 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
     L.id = ids;
     L.geo = geo;
     L.n_spheres = n_sph;
+    L.sc = &sc;
     L.stack = reinterpret_cast<unsigned short*>(geo + n_sph + 2u * sc.n_rects) + threadIdx.x;
     return L;
 }
@@ -252,11 +270,23 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
         float th;
         // candidate root of this primitive (independent of tbest), then the order-independent accept
         bool ok;
-        if (!RECTS || (uint32_t)s < L.n_spheres) {
+        if (!RECTS) {
             ok = sphere_root(L.geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th);
         } else {
-            const uint32_t gi = L.n_spheres + 2u * ((uint32_t)s - L.n_spheres);
-            ok = rect_root(L.geo[gi], L.geo[gi + 1u], o, d, 1e-3f, RT_FLT_MAX, th);
+            // general scene: the primitive may sit below Translate / RotateY wrappers (t is unchanged by them)
+            V3 po = o, pd = d;
+            float pa = a;
+            const uint32_t xf = L.sc->prim_xform[s];
+            if (xf != RT_NO_XFORM_DEV) {
+                chain_to_object(*L.sc, load_chain(*L.sc, xf), po, pd);
+                pa = length_squared(pd); // hitable.rs:77 on the rotated direction
+            }
+            if ((uint32_t)s < L.n_spheres) {
+                ok = sphere_root(L.geo[s], po, pd, pa, 1e-3f, RT_FLT_MAX, th);
+            } else {
+                const uint32_t gi = L.n_spheres + 2u * ((uint32_t)s - L.n_spheres);
+                ok = rect_root(L.geo[gi], L.geo[gi + 1u], po, pd, 1e-3f, RT_FLT_MAX, th);
+            }
         }
         if (ok && (th < tbest || (th == tbest && s > hit))) {
             tbest = th;
@@ -388,7 +418,9 @@ __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float
         float tbest = RT_FLT_MAX;
         int hit = -1;
         const float a = length_squared(d);
-        if (single_tile) {
+        if (sc.n_xforms) {
+            closest_hit_spheres_general(sc, o, d, tbest, hit);
+        } else if (single_tile) {
             closest_hit_tile(s_geo, n_sph, 0u, o, d, a, tbest, hit);
         } else {
             for (uint32_t t0 = 0; t0 < n_sph; t0 += RT_SPHERE_TILE) {
@@ -662,12 +694,16 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
         }
     } else {
         float4* s_geo = reinterpret_cast<float4*>(smem);
-        for (uint32_t t0 = 0; t0 < sc.n_spheres; t0 += RT_SPHERE_TILE) {
-            const uint32_t nn = min(RT_SPHERE_TILE, sc.n_spheres - t0);
-            __syncthreads();
-            for (uint32_t k = threadIdx.x; k < nn; k += BLOCK) s_geo[k] = sc.sph_geo[t0 + k];
-            __syncthreads();
-            closest_hit_tile(s_geo, nn, t0, o, d, a, tbest, hit);
+        if (sc.n_xforms) {
+            closest_hit_spheres_general(sc, o, d, tbest, hit);
+        } else {
+            for (uint32_t t0 = 0; t0 < sc.n_spheres; t0 += RT_SPHERE_TILE) {
+                const uint32_t nn = min(RT_SPHERE_TILE, sc.n_spheres - t0);
+                __syncthreads();
+                for (uint32_t k = threadIdx.x; k < nn; k += BLOCK) s_geo[k] = sc.sph_geo[t0 + k];
+                __syncthreads();
+                closest_hit_tile(s_geo, nn, t0, o, d, a, tbest, hit);
+            }
         }
         closest_hit_rects(sc, o, d, tbest, hit);
     }

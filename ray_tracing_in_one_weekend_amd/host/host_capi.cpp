@@ -192,6 +192,23 @@ uint32_t rth_gbox(RthScene* s, const float mn[3], const float mx[3], uint32_t ma
     });
 }
 
+// Replaces world entry `hitable` (a handle returned by rth_sphere/rth_rect/rth_gbox/rth_translate/rth_rotate_y)
+// by the wrapper around it, like `let box_1 = Arc::new(RotateY::new(box_1, 15.))` (demo_scene.rs:121-122).
+uint32_t rth_translate(RthScene* s, uint32_t hitable, const float offset[3]) {
+    return guarded_handle([&]() -> uint32_t {
+        if (hitable >= s->world.size()) throw std::runtime_error("rth_translate: bad hitable handle");
+        s->world[hitable] = std::make_shared<Translate>(v(offset), s->world[hitable]);
+        return hitable;
+    });
+}
+uint32_t rth_rotate_y(RthScene* s, uint32_t hitable, float angle_degrees) {
+    return guarded_handle([&]() -> uint32_t {
+        if (hitable >= s->world.size()) throw std::runtime_error("rth_rotate_y: bad hitable handle");
+        s->world[hitable] = RotateY::new_(s->world[hitable], angle_degrees);
+        return hitable;
+    });
+}
+
 int rth_set_sky(RthScene* s, uint32_t sky, const char* env_path) {
     return guarded([&] {
         (void)s;

@@ -4,6 +4,7 @@
 //   Camera::new_(lookfrom, lookat, vup, vfov_deg, aspect)      camera.rs:14-39
 //   Sphere{c, r, mat, name}                                    hitable.rs:57-62
 //   XYRect/XZRect/YZRect{min, max, mat}, GBox::new_(min,max,mat)  hitable.rs:244-402
+//   Translate{offset, ptr}, RotateY::new_(ptr, angle)          hitable.rs:404-520
 //   HitableList = vector<shared_ptr<Hitable>>                  hitable.rs:114
 //   BvhNode::new_(objects, start, end)                         hitable.rs:177-221
 //   Emission{emit} Diffuse{albedo} Lambert{albedo} Metal{albedo,fuzz} Dielectric{ior}
@@ -153,10 +154,27 @@ class FlatSceneBuilder {
         rect_axis.push_back(axis);
         push3(rect_min, mn), push3(rect_max, mx);
         rect_mat.push_back(mat);
+        rect_xform.push_back(cur_xform);
     }
     void push_sphere(Vec3A c, float r, uint32_t mat, const std::string& name) {
         sph_cx.push_back(c.x), sph_cy.push_back(c.y), sph_cz.push_back(c.z), sph_r.push_back(r), sph_mat.push_back(mat);
         sph_name.push_back(name);
+        sph_xform.push_back(cur_xform);
+    }
+    // Opens an instance wrapper (hitable.rs:404-520): primitives pushed until the matching
+    // pop_xform() lie below it.  Returns the previous innermost wrapper (to restore).
+    uint32_t push_xform(uint8_t type, float p0, float p1, float p2) {
+        xf_type.push_back(type);
+        xf_param.push_back(p0), xf_param.push_back(p1), xf_param.push_back(p2), xf_param.push_back(0.0f);
+        xf_parent.push_back(cur_xform);
+        const uint32_t prev = cur_xform;
+        cur_xform = (uint32_t)xf_type.size() - 1;
+        if (++xform_depth > RT_MAX_XFORM_CHAIN) throw std::runtime_error("flatten: more than RT_MAX_XFORM_CHAIN nested Translate/RotateY");
+        return prev;
+    }
+    void pop_xform(uint32_t prev) {
+        cur_xform = prev;
+        --xform_depth;
     }
     RtFlatScene view() const {
         RtFlatScene s;
@@ -166,6 +184,9 @@ class FlatSceneBuilder {
         s.sph_mat = sph_mat.data();
         s.n_rects = (uint32_t)rect_axis.size();
         s.rect_axis = rect_axis.data(), s.rect_min = rect_min.data(), s.rect_max = rect_max.data(), s.rect_mat = rect_mat.data();
+        s.n_xforms = (uint32_t)xf_type.size();
+        s.xf_type = xf_type.data(), s.xf_param = xf_param.data(), s.xf_parent = xf_parent.data();
+        s.sph_xform = sph_xform.data(), s.rect_xform = rect_xform.data();
         s.n_materials = (uint32_t)mat_type.size();
         s.mat_type = mat_type.data(), s.mat_color = mat_color.data();
         s.mat_p0 = mat_p0.data(), s.mat_p1 = mat_p1.data(), s.mat_p2 = mat_p2.data(), s.mat_p3 = mat_p3.data();
@@ -188,6 +209,10 @@ class FlatSceneBuilder {
     std::vector<uint8_t> rect_axis;
     std::vector<float> rect_min, rect_max;
     std::vector<uint32_t> rect_mat;
+    std::vector<uint8_t> xf_type;
+    std::vector<float> xf_param;
+    std::vector<uint32_t> xf_parent, sph_xform, rect_xform;
+    uint32_t cur_xform = RT_NO_XFORM, xform_depth = 0;
     std::vector<uint8_t> mat_type;
     std::vector<float> mat_color, mat_p0, mat_p1, mat_p2, mat_p3;
     std::vector<uint32_t> mat_tex0, mat_tex1;
@@ -476,6 +501,43 @@ class GBox : public Hitable {
 
   private:
     HitableList sides_;
+};
+
+// hitable.rs:404-436 — Translate { offset, ptr }
+struct Translate : Hitable {
+    Vec3A offset;
+    HitablePtr ptr;
+    Translate(Vec3A o, HitablePtr p) : offset(o), ptr(std::move(p)) {}
+    void flatten(FlatSceneBuilder& b) const override {
+        const uint32_t prev = b.push_xform(RT_XF_TRANSLATE, offset.x, offset.y, offset.z);
+        ptr->flatten(b);
+        b.pop_xform(prev);
+    }
+    std::string memo() const override { throw std::runtime_error("Translate::memo: todo!() in the reference (hitable.rs:433-435)"); }
+};
+
+// hitable.rs:438-520 — RotateY::new(ptr, angle_degrees); sin/cos exactly as radians.sin_cos() of f32::to_radians
+class RotateY : public Hitable {
+  public:
+    static std::shared_ptr<RotateY> new_(HitablePtr ptr, float angle) {
+        auto r = std::shared_ptr<RotateY>(new RotateY());
+        r->ptr_ = std::move(ptr);
+        r->angle_ = angle;
+        const float radians = angle * (3.14159265358979323846f / 180.0f);
+        r->sin_theta_ = std::sin(radians);
+        r->cos_theta_ = std::cos(radians);
+        return r;
+    }
+    void flatten(FlatSceneBuilder& b) const override {
+        const uint32_t prev = b.push_xform(RT_XF_ROTATE_Y, sin_theta_, cos_theta_, angle_);
+        ptr_->flatten(b);
+        b.pop_xform(prev);
+    }
+    std::string memo() const override { throw std::runtime_error("RotateY::memo: todo!() in the reference (hitable.rs:517-519)"); }
+
+  private:
+    HitablePtr ptr_;
+    float angle_ = 0, sin_theta_ = 0, cos_theta_ = 1;
 };
 
 // hitable.rs:158-221.  The accelerated path does its own closest-hit search, so the mirror

@@ -466,3 +466,64 @@ def test_repeated_renders_reuploads_and_contexts(rt):
     a.close()
     b.close()
     assert free0 - free_bytes() < (64 << 20)  # everything the two contexts allocated is released
+
+
+def _cornell_with_instances(rt):
+    """demo_scene.rs:112-148 without the smoke: the two boxes are RotateY + Translate instances of GBox
+    (hitable.rs:404-520) used as solid white boxes, plus a translated/rotated sphere."""
+    s = rt.Scene.new()
+    f = rt._ffi
+    red = s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.65, 0.05, 0.05)))
+    white = s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.73, 0.73, 0.73)))
+    green = s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.12, 0.45, 0.15)))
+    light = s.material(f.MAT_EMISSION, tex0=s.constant_tex((7, 7, 7)))
+    s.rect(f.RECT_XZ, (113, 554, 127), (443, 554, 432), light)
+    s.rect(f.RECT_XY, (0, 0, 555), (555, 555, 555), white)
+    s.rect(f.RECT_XZ, (0, 0, 0), (555, 0, 555), white)
+    s.rect(f.RECT_XZ, (0, 555, 0), (555, 555, 555), white)
+    s.rect(f.RECT_YZ, (0, 0, 0), (0, 555, 555), red)
+    s.rect(f.RECT_YZ, (555, 0, 0), (555, 555, 555), green)
+    b1 = s.gbox((0, 0, 0), (165, 330, 165), white)
+    s.rotate_y(b1, 15.0)
+    s.translate(b1, (265, 0, 295))
+    b2 = s.gbox((0, 0, 0), (165, 165, 165), s.material(f.MAT_LAMBERT, tex0=s.image_tex("res/earthmap.jpg")))
+    s.rotate_y(b2, -18.0)
+    s.translate(b2, (130, 0, 65))
+    sp = s.sphere((0, 0, 0), 50.0, s.material(f.MAT_DIELECTRIC, p=(1.5,)), "glass")
+    s.translate(sp, (30, 215, 40))
+    s.rotate_y(sp, 30.0)       # nesting the other way round: RotateY(Translate(sphere))
+    s.translate(sp, (200, 0, 60))
+    s.set_sky(f.SKY_BLACK)
+    s.set_camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40, 1.0)
+    return s.finish()
+
+
+def test_translate_and_rotate_y_instances(rt, orc, renderer):
+    scene = _cornell_with_instances(rt)
+    a = scene.arrays()
+    assert scene.flat.n_xforms == 7 and a["xf_type"].tolist() == [0, 1, 0, 1, 0, 1, 0]
+    assert a["xf_parent"].tolist() == [rt._ffi.NO_XFORM, 0, rt._ffi.NO_XFORM, 2, rt._ffi.NO_XFORM, 4, 5]
+    renderer.upload(scene)
+    rng = np.random.default_rng(9)
+    n = 30000
+    o = rng.uniform(5, 550, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    ln = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]).astype(np.float32)
+    d = (d * (np.float32(1) / ln)[:, None]).astype(np.float32)
+    keys = rng.integers(0, 2**32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+    g = renderer.debug_bounce(o, d, keys)
+    b = renderer.debug_bounce(o, d, keys, flags=rt._ffi.FLAG_BRUTE_FORCE)
+    c = orc.debug_bounce(scene.flat_ptr, o, d, keys, accel=orc.ACCEL_LIST)
+    for other in (b, c):
+        assert np.array_equal(g["hit"], other["hit"]) and np.array_equal(g["t"].view(np.uint32), other["t"].view(np.uint32))
+        assert np.array_equal(g["alive"], other["alive"])
+        assert np.array_equal(g["o"].view(np.uint32), other["o"].view(np.uint32))
+        assert np.array_equal(g["d"].view(np.uint32), other["d"].view(np.uint32))
+    assert np.allclose(g["attenuation"], c["attenuation"], rtol=2e-5, atol=1e-6)
+    inst = (g["hit"] == 0) | (g["hit"] >= 1 + 6)  # the wrapped sphere (prim 0) or a side of a wrapped box
+    assert inst.mean() > 0.15
+    p = rt.make_params(160, 160, 16, max_depth=50)
+    img, _, st = renderer.render(scene.camera, p)
+    ref, _, so = _oracle(orc, scene, p, accel=orc.ACCEL_LIST)
+    assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
+    assert st.n_texture_fetches == so.n_texture_fetches and rmse_display(img, ref) <= RMSE_TOL
