@@ -39,7 +39,7 @@ int rth_register_image(const char* path, uint32_t w, uint32_t h, const float* rg
 void rth_rng_reseed(uint64_t seed);
 
 /* Runs a named scene function: "sphere_scene", "test_sphere", "simple_light_scene",
- * "earth_env_scene", "pbr_sweep_scene"; flattens world + sky + camera.  The thread RNG is reset to its
+ * "cornell_box", "earth_env_scene", "pbr_sweep_scene"; flattens world + sky + camera.  The thread RNG is reset to its
  * fresh-process state (seed 1995) first, so repeated builds give identical Perlin tables. */
 int rth_scene_build(const char* name, float aspect_ratio, RthScene** out);
 
@@ -60,6 +60,8 @@ uint32_t rth_gbox(RthScene* s, const float mn[3], const float mx[3], uint32_t ma
  * the handle stays valid and now denotes the wrapper (wrappers nest, outermost applied last) */
 uint32_t rth_translate(RthScene* s, uint32_t hitable, const float offset[3]);
 uint32_t rth_rotate_y(RthScene* s, uint32_t hitable, float angle_degrees);
+/* hitable.rs:529-533: turn the world entry `hitable` into ConstantMedium::new(hitable, density, phase_tex) */
+uint32_t rth_constant_medium(RthScene* s, uint32_t hitable, float density, uint32_t phase_tex);
 /* sky = RtSkyType; env_path only for RT_SKY_ENV */
 int rth_set_sky(RthScene* s, uint32_t sky, const char* env_path);
 int rth_set_camera(RthScene* s, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3u
+#define RT_ABI_VERSION 4u
 
 /* error codes */
 #define RT_OK 0
@@ -96,14 +96,17 @@ enum RtXformType {
 #define RT_NO_XFORM 0xFFFFFFFFu
 #define RT_MAX_XFORM_CHAIN 4u /* nesting depth the kernels support */
 
+#define RT_NO_MEDIUM 0xFFFFFFFFu
+#define RT_MAX_MEDIA 32u /* the medium's random draw uses counter slot 224 + medium index of its depth block */
+
 #define RT_NO_TEX 0xFFFFFFFFu
 #define RT_PERLIN_POINTS 256u /* texture.rs:51 */
 
 /*
  * Flattened structure-of-arrays scene.  Replaces `Vec<Arc<dyn Hitable>>` + the trait
  * objects behind it (hitable.rs:57-62, material.rs, pbr.rs, texture.rs).  Spheres (SURVEY.md
- * §8(a) a4), axis-aligned rectangles / boxes and the Translate / RotateY instance wrappers
- * (§8(f) rank 1) are on the accelerated path; ConstantMedium is not yet.
+ * §8(a) a4), axis-aligned rectangles / boxes, the Translate / RotateY instance wrappers (§8(f)
+ * rank 1) and ConstantMedium (§8(f) rank 2) are on the accelerated path.
  */
 typedef struct RtFlatScene {
     /* spheres: hitable.rs:57-62 `Sphere { c, r, mat, name }` in world-list order */
@@ -131,6 +134,17 @@ typedef struct RtFlatScene {
     const uint32_t* xf_parent;  /* [n_xforms] next wrapper outwards or RT_NO_XFORM */
     const uint32_t* sph_xform;  /* [n_spheres] innermost wrapper or RT_NO_XFORM; NULL = none */
     const uint32_t* rect_xform; /* [n_rects]   likewise */
+
+    /* homogeneous media: hitable.rs:523-588 `ConstantMedium::new(boundary, density, phase_tex)`.
+     * The boundary's primitives are flattened like any others but tagged with the medium that owns
+     * them (sph_medium / rect_medium); tagged primitives are NOT hit directly — medium i is primitive
+     * n_spheres + n_rects + i and its hit() does the two boundary queries and the one random draw of
+     * hitable.rs:540-568.  Its material is the Isotropic phase function (material.rs:99-113). */
+    uint32_t n_media;
+    const float* med_neg_inv_density; /* [n_media] -1/density */
+    const uint32_t* med_mat;          /* [n_media] material index (RT_MAT_ISOTROPIC) */
+    const uint32_t* sph_medium;       /* [n_spheres] owning medium or RT_NO_MEDIUM; NULL = none */
+    const uint32_t* rect_medium;      /* [n_rects] likewise */
 
     /* materials */
     uint32_t n_materials;

@@ -269,6 +269,7 @@ struct Rng {
     bool counter;
     Xoshiro256pp xo;
     uint32_t k0, k1, ctr;
+    uint32_t base = 0; /* first counter of the current depth block */
     float next_f32() {
         if (counter) {
             uint32_t r = ctr_draw(k0, k1, ctr++);
@@ -277,9 +278,16 @@ struct Rng {
         return xo.next_f32();
     }
     void set_depth(int depth) {
-        if (counter) ctr = (uint32_t)(depth + 1) * 256u;
+        if (counter) ctr = base = (uint32_t)(depth + 1) * 256u;
     }
 };
+/* The one f32 a ConstantMedium draws inside hit() (hitable.rs:564).  Stream mode: the next value of the
+ * stream, in traversal order like the reference.  Counter mode: slot 224 + medium index of the depth block,
+ * so the value does not depend on the order in which media are visited. */
+inline float rng_medium_draw(Rng& rng, uint32_t m) {
+    if (!rng.counter) return rng.xo.next_f32();
+    return (float)(ctr_draw(rng.k0, rng.k1, rng.base + 224u + m) >> 8) * (1.0f / 16777216.0f);
+}
 
 /* ------------------------------------------------------------------------------------------
  * math.rs
@@ -570,13 +578,63 @@ inline AABB xform_bbox(const RtFlatScene& fs, uint32_t x, const AABB& b) {
     return AABB{mn, mx};
 }
 
-/* hitable.rs:117-132 HitableList::hit over the flat primitive list (world order). */
-inline bool list_hit(const RtFlatScene& fs, const Ray& r, float t_min, float t_max, HitRecord& rec) {
+/* ---- ConstantMedium, hitable.rs:523-588 ---------------------------------------------------- */
+inline uint32_t prim_medium(const RtFlatScene& fs, int i) {
+    if (i < (int)fs.n_spheres) return fs.sph_medium ? fs.sph_medium[i] : RT_NO_MEDIUM;
+    return fs.rect_medium ? fs.rect_medium[i - (int)fs.n_spheres] : RT_NO_MEDIUM;
+}
+/* boundary.hit(r, t_min, t_max, rec): the boundary object is the list of primitives tagged with medium m
+ * (a GBox's sides through its wrappers, or one sphere): closest hit in list order */
+inline bool boundary_hit(const RtFlatScene& fs, uint32_t m, const Ray& r, float t_min, float t_max, HitRecord& rec) {
     HitRecord temp_rec;
     float closest_so_far = t_max;
     bool hit_anything = false;
     for (uint32_t i = 0; i < fs.n_spheres + fs.n_rects; ++i) {
+        if (prim_medium(fs, (int)i) != m) continue;
         if (prim_hit_x(fs, (int)i, r, t_min, closest_so_far, temp_rec)) {
+            hit_anything = true;
+            closest_so_far = temp_rec.t;
+        }
+    }
+    if (hit_anything) rec = temp_rec;
+    return hit_anything;
+}
+inline bool medium_hit(const RtFlatScene& fs, uint32_t m, const Ray& r, float t_min, float t_max, HitRecord& rec, Rng& rng) {
+    /* hitable.rs:536-579 (ENABLE_DEBUGGING = false: the debugging draw is short-circuited away) */
+    HitRecord rec_1, rec_2;
+    if (!boundary_hit(fs, m, r, -INFINITY, INFINITY, rec_1)) return false;
+    if (!boundary_hit(fs, m, r, rec_1.t + 0.0001f, INFINITY, rec_2)) return false;
+    if (rec_1.t < t_min) rec_1.t = t_min;
+    if (rec_2.t > t_max) rec_2.t = t_max;
+    if (rec_1.t >= rec_2.t) return false;
+    if (rec_1.t < 0.0f) rec_1.t = 0.0f;
+    float ray_len = length(r.d);
+    float dist_inside_boundary = (rec_2.t - rec_1.t) * ray_len;
+    float hit_dist = fs.med_neg_inv_density[m] * std::log(rng_medium_draw(rng, m));
+    if (hit_dist > dist_inside_boundary) return false;
+    rec.t = rec_1.t + hit_dist / ray_len;
+    rec.p = ray_at(r, rec.t);
+    rec.norm = v3(1.0f, 0.0f, 0.0f);
+    rec.front_face = true;
+    rec.mat = (int)fs.med_mat[m];
+    rec.prim = (int)(fs.n_spheres + fs.n_rects + m);
+    return true; /* uv and tang keep whatever an earlier candidate left (not written, hitable.rs:574-576) */
+}
+
+/* hitable.rs:117-132 HitableList::hit over the flat primitive list (world order). */
+/* any world entry: primitive i < n_spheres + n_rects (unless it only bounds a medium), else medium */
+inline bool entry_hit(const RtFlatScene& fs, int i, const Ray& r, float t_min, float t_max, HitRecord& rec, Rng& rng) {
+    const int np = (int)(fs.n_spheres + fs.n_rects);
+    if (i >= np) return medium_hit(fs, (uint32_t)(i - np), r, t_min, t_max, rec, rng);
+    if (prim_medium(fs, i) != RT_NO_MEDIUM) return false;
+    return prim_hit_x(fs, i, r, t_min, t_max, rec);
+}
+inline bool list_hit(const RtFlatScene& fs, const Ray& r, float t_min, float t_max, HitRecord& rec, Rng& rng) {
+    HitRecord temp_rec;
+    float closest_so_far = t_max;
+    bool hit_anything = false;
+    for (uint32_t i = 0; i < fs.n_spheres + fs.n_rects + fs.n_media; ++i) {
+        if (entry_hit(fs, (int)i, r, t_min, closest_so_far, temp_rec, rng)) {
             hit_anything = true;
             closest_so_far = temp_rec.t;
         }
@@ -594,8 +652,16 @@ struct Bvh {
     std::vector<BvhNode> nodes;
     int root = -1;
 };
+inline AABB sphere_bbox(const RtFlatScene& fs, int idx); /* fwd */
+inline AABB medium_bbox(const RtFlatScene& fs, uint32_t m) { /* hitable.rs:581-583: the boundary's box */
+    AABB b{splat(INFINITY), splat(-INFINITY)};
+    for (uint32_t i = 0; i < fs.n_spheres + fs.n_rects; ++i)
+        if (prim_medium(fs, (int)i) == m) b = aabb_surround(b, sphere_bbox(fs, (int)i));
+    return b;
+}
 inline AABB sphere_bbox(const RtFlatScene& fs, int idx) { /* hitable.rs:104-108; wrapped primitives: world bounds */
     AABB b;
+    if (idx >= (int)(fs.n_spheres + fs.n_rects)) return medium_bbox(fs, (uint32_t)idx - fs.n_spheres - fs.n_rects);
     if (idx >= (int)fs.n_spheres) {
         b = rect_bbox(fs, idx - (int)fs.n_spheres);
     } else {
@@ -644,12 +710,12 @@ int bvh_build(const RtFlatScene& fs, Bvh& bvh, std::vector<int>& objects, size_t
     return (int)bvh.nodes.size() - 1;
 }
 bool bvh_hit(const RtFlatScene& fs, const Bvh& bvh, int node, const Ray& r, float t_min, float t_max,
-             HitRecord& rec) { /* hitable.rs:232-240 */
-    if (node < 0) return prim_hit_x(fs, ~node, r, t_min, t_max, rec);
+             HitRecord& rec, Rng& rng) { /* hitable.rs:232-240 */
+    if (node < 0) return entry_hit(fs, ~node, r, t_min, t_max, rec, rng);
     const BvhNode& n = bvh.nodes[(size_t)node];
     if (!aabb_hit(n.box, r, t_min, t_max)) return false;
-    bool hit_left = bvh_hit(fs, bvh, n.left, r, t_min, t_max, rec);
-    bool hit_right = bvh_hit(fs, bvh, n.right, r, t_min, hit_left ? rec.t : t_max, rec);
+    bool hit_left = bvh_hit(fs, bvh, n.left, r, t_min, t_max, rec, rng);
+    bool hit_right = bvh_hit(fs, bvh, n.right, r, t_min, hit_left ? rec.t : t_max, rec, rng);
     return hit_left || hit_right;
 }
 
@@ -1009,15 +1075,15 @@ bool mat_scatter(Ctx& cx, Rng& rng, int m, const Ray& r_in, const HitRecord& rec
     }
 }
 
-inline bool world_hit(Ctx& cx, const Ray& r, float t_min, float t_max, HitRecord& rec) {
+inline bool world_hit(Ctx& cx, Rng& rng, const Ray& r, float t_min, float t_max, HitRecord& rec) {
     if (cx.bvh) {
         /* world = vec![BvhNode] (demo_scene.rs:223-227) walked by HitableList::hit */
         HitRecord temp_rec;
-        bool h = bvh_hit(*cx.fs, *cx.bvh, cx.bvh->root, r, t_min, t_max, temp_rec);
+        bool h = bvh_hit(*cx.fs, *cx.bvh, cx.bvh->root, r, t_min, t_max, temp_rec, rng);
         if (h) rec = temp_rec;
         return h;
     }
-    return list_hit(*cx.fs, r, t_min, t_max, rec);
+    return list_hit(*cx.fs, r, t_min, t_max, rec, rng);
 }
 
 /* main.rs:38-60 ray_color, recursive exactly as the reference. */
@@ -1031,7 +1097,7 @@ V3 ray_color(Ctx& cx, Rng& rng, const Ray& r, int depth) {
     if (depth < 64) ++cx.per_depth[depth];
     rng.set_depth(depth);
     HitRecord rec;
-    if (world_hit(cx, r, 1e-3f, std::numeric_limits<float>::max(), rec)) {
+    if (world_hit(cx, rng, r, 1e-3f, std::numeric_limits<float>::max(), rec)) {
         Ray scattered{splat(0.0f), splat(0.0f)};
         V3 attenuation = splat(1.0f);
         V3 ret = mat_emitted(cx, rec.mat, rec.uv, rec.p);
@@ -1064,7 +1130,7 @@ V3 ray_color_iterative(Ctx& cx, Rng& rng, Ray r) {
         if (depth < 64) ++cx.per_depth[depth];
         rng.set_depth(depth);
         HitRecord rec;
-        if (!world_hit(cx, r, 1e-3f, std::numeric_limits<float>::max(), rec)) {
+        if (!world_hit(cx, rng, r, 1e-3f, std::numeric_limits<float>::max(), rec)) {
             return T * sky_value(*cx.fs, r.d, &cx.n_tex);
         }
         Ray scattered{splat(0.0f), splat(0.0f)};
@@ -1119,12 +1185,24 @@ static void perlin_default(Xoshiro256pp& rng, float* vec_out, uint16_t* perm_out
     }
 }
 
+/* world-list entries that the BVH is built over: primitives that do not merely bound a medium, then the media */
+static std::vector<int> world_entries(const RtFlatScene* fs) {
+    std::vector<int> objects;
+    const uint32_t np = fs->n_spheres + fs->n_rects;
+    for (uint32_t i = 0; i < np + fs->n_media; ++i)
+        if (i >= np || prim_medium(*fs, (int)i) == RT_NO_MEDIUM) objects.push_back((int)i);
+    return objects;
+}
+
 static int validate_scene(const RtFlatScene* fs) {
     if (!fs) return RT_ERR_INVALID;
     for (uint32_t i = 0; i < fs->n_spheres; ++i)
         if (fs->sph_mat[i] >= fs->n_materials) return RT_ERR_INVALID;
     for (uint32_t i = 0; i < fs->n_rects; ++i)
         if (fs->rect_mat[i] >= fs->n_materials || fs->rect_axis[i] > RT_RECT_XY) return RT_ERR_INVALID;
+    if (fs->n_media > RT_MAX_MEDIA) return RT_ERR_INVALID;
+    for (uint32_t i = 0; i < fs->n_media; ++i)
+        if (fs->med_mat[i] >= fs->n_materials) return RT_ERR_INVALID;
     for (uint32_t i = 0; i < fs->n_xforms; ++i)
         if (fs->xf_type[i] > RT_XF_ROTATE_Y || (fs->xf_parent[i] != RT_NO_XFORM && fs->xf_parent[i] >= i)) return RT_ERR_INVALID;
     return RT_OK;
@@ -1157,11 +1235,10 @@ int orc_render(const RtFlatScene* fs, const RtCamera* cam, const RtParams* prm, 
     const size_t nrows = rows.size();
 
     Bvh bvh;
-    if (opt->accel == 1 && fs->n_spheres + fs->n_rects > 0) {
+    if (opt->accel == 1 && !world_entries(fs).empty()) {
         Xoshiro256pp main_rng = smallrng_seed_from_u64(opt->bvh_seed);
         for (uint32_t k = 0; k < opt->bvh_skip_perlin; ++k) perlin_default(main_rng, nullptr, nullptr);
-        std::vector<int> objects(fs->n_spheres + fs->n_rects);
-        for (uint32_t i = 0; i < fs->n_spheres + fs->n_rects; ++i) objects[i] = (int)i;
+        std::vector<int> objects = world_entries(fs);
         bvh.root = bvh_build(*fs, bvh, objects, 0, objects.size(), main_rng);
     }
 
@@ -1263,10 +1340,9 @@ int orc_render(const RtFlatScene* fs, const RtCamera* cam, const RtParams* prm, 
 int orc_debug_bounce(const RtFlatScene* fs, const RtBounceIO* io, uint32_t accel) {
     if (validate_scene(fs) != RT_OK || !io) return RT_ERR_INVALID;
     Bvh bvh;
-    if (accel == 1 && fs->n_spheres + fs->n_rects > 0) {
+    if (accel == 1 && !world_entries(fs).empty()) {
         Xoshiro256pp main_rng = smallrng_seed_from_u64(1995);
-        std::vector<int> objects(fs->n_spheres + fs->n_rects);
-        for (uint32_t i = 0; i < fs->n_spheres + fs->n_rects; ++i) objects[i] = (int)i;
+        std::vector<int> objects = world_entries(fs);
         bvh.root = bvh_build(*fs, bvh, objects, 0, objects.size(), main_rng);
     }
     Ctx cx;
@@ -1278,6 +1354,7 @@ int orc_debug_bounce(const RtFlatScene* fs, const RtBounceIO* io, uint32_t accel
         Rng rng;
         rng.counter = true;
         rng.k0 = io->in_key[2 * n], rng.k1 = io->in_key[2 * n + 1];
+        rng.ctr = 0;
         rng.set_depth((int)io->depth);
         HitRecord rec;
         V3 rad = splat(0.0f), att = splat(1.0f);
@@ -1285,7 +1362,7 @@ int orc_debug_bounce(const RtFlatScene* fs, const RtBounceIO* io, uint32_t accel
         bool alive = false;
         int hit = -1;
         float t = 0.0f;
-        if (world_hit(cx, r, 1e-3f, std::numeric_limits<float>::max(), rec)) {
+        if (world_hit(cx, rng, r, 1e-3f, std::numeric_limits<float>::max(), rec)) {
             hit = rec.prim;
             t = rec.t;
             rad = mat_emitted(cx, rec.mat, rec.uv, rec.p);
@@ -1459,8 +1536,7 @@ uint32_t orc_bvh_stats(const RtFlatScene* fs, uint64_t seed, uint32_t skip_perli
     Bvh bvh;
     Xoshiro256pp main_rng = smallrng_seed_from_u64(seed);
     for (uint32_t k = 0; k < skip_perlin; ++k) perlin_default(main_rng, nullptr, nullptr);
-    std::vector<int> objects(fs->n_spheres + fs->n_rects);
-    for (uint32_t i = 0; i < fs->n_spheres + fs->n_rects; ++i) objects[i] = (int)i;
+    std::vector<int> objects = world_entries(fs);
     bvh.root = bvh_build(*fs, bvh, objects, 0, objects.size(), main_rng);
     if (n_nodes) *n_nodes = (uint32_t)bvh.nodes.size();
     return (uint32_t)bvh.root;

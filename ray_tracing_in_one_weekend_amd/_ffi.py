@@ -47,6 +47,8 @@ class RtFlatScene(C.Structure):
         ("rect_axis", _u8), ("rect_min", _f), ("rect_max", _f), ("rect_mat", _u32),
         ("n_xforms", C.c_uint32),
         ("xf_type", _u8), ("xf_param", _f), ("xf_parent", _u32), ("sph_xform", _u32), ("rect_xform", _u32),
+        ("n_media", C.c_uint32),
+        ("med_neg_inv_density", _f), ("med_mat", _u32), ("sph_medium", _u32), ("rect_medium", _u32),
         ("n_materials", C.c_uint32),
         ("mat_type", _u8), ("mat_color", _f), ("mat_p0", _f), ("mat_p1", _f), ("mat_p2", _f), ("mat_p3", _f),
         ("mat_tex0", _u32), ("mat_tex1", _u32),
@@ -95,7 +97,7 @@ GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_err
                "rt_get_depth_timings"]
 HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
                 "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
-                "rth_sphere", "rth_rect", "rth_gbox", "rth_translate", "rth_rotate_y", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
+                "rth_sphere", "rth_rect", "rth_gbox", "rth_translate", "rth_rotate_y", "rth_constant_medium", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
                 "rth_scene_camera", "rth_scene_sphere_name", "rth_scene_free"]
 
 _gpu_lib = None
@@ -181,6 +183,8 @@ def load_host_library():
     lib.rth_translate.restype = C.c_uint32
     lib.rth_rotate_y.argtypes = [vp, C.c_uint32, C.c_float]
     lib.rth_rotate_y.restype = C.c_uint32
+    lib.rth_constant_medium.argtypes = [vp, C.c_uint32, C.c_float, C.c_uint32]
+    lib.rth_constant_medium.restype = C.c_uint32
     lib.rth_set_sky.argtypes = [vp, C.c_uint32, C.c_char_p]
     lib.rth_set_sky.restype = C.c_int
     lib.rth_set_camera.argtypes = [vp, f3, f3, f3, C.c_float, C.c_float]

@@ -84,6 +84,9 @@ class Scene:
     def rotate_y(self, hitable, angle_degrees):
         return self._check(self._lib.rth_rotate_y(self._h, hitable, C.c_float(angle_degrees)))
 
+    def constant_medium(self, hitable, density, phase_tex):
+        return self._check(self._lib.rth_constant_medium(self._h, hitable, C.c_float(density), phase_tex))
+
     def set_sky(self, sky, env_path=None):
         if self._lib.rth_set_sky(self._h, sky, env_path.encode() if env_path else None) != 0:
             raise RtError(self._lib.rth_last_error().decode())
@@ -141,6 +144,8 @@ class Scene:
             "xf_type": arr(fs.xf_type, fs.n_xforms, np.uint8), "xf_param": arr(fs.xf_param, 4 * fs.n_xforms, np.float32),
             "xf_parent": arr(fs.xf_parent, fs.n_xforms, np.uint32), "sph_xform": arr(fs.sph_xform, ns, np.uint32),
             "rect_xform": arr(fs.rect_xform, fs.n_rects, np.uint32),
+            "med_neg_inv_density": arr(fs.med_neg_inv_density, fs.n_media, np.float32), "med_mat": arr(fs.med_mat, fs.n_media, np.uint32),
+            "sph_medium": arr(fs.sph_medium, ns, np.uint32), "rect_medium": arr(fs.rect_medium, fs.n_rects, np.uint32),
             "mat_type": arr(fs.mat_type, nm, np.uint8), "mat_color": arr(fs.mat_color, 3 * nm, np.float32),
             "mat_p0": arr(fs.mat_p0, nm, np.float32), "mat_p1": arr(fs.mat_p1, nm, np.float32),
             "mat_p2": arr(fs.mat_p2, nm, np.float32), "mat_p3": arr(fs.mat_p3, nm, np.float32),

@@ -229,6 +229,21 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         if (!chain_ok(s->sph_xform[i])) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad sphere transform chain");
     for (uint32_t i = 0; i < s->n_rects && s->rect_xform; ++i)
         if (!chain_ok(s->rect_xform[i])) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad rectangle transform chain");
+    if (s->n_media > RT_MAX_MEDIA) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: more than RT_MAX_MEDIA media");
+    if (s->n_media && (!s->med_neg_inv_density || !s->med_mat))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: medium arrays missing");
+    for (uint32_t m = 0; m < s->n_media; ++m) {
+        if (s->med_mat[m] >= s->n_materials) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: medium material out of range");
+        const uint32_t mt = s->mat_type[s->med_mat[m]];
+        // a medium writes neither uv nor tang (hitable.rs:574-576): materials that read them see stale record state
+        if (mt == RT_MAT_DISNEY_METAL) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: DisneyMetal as a phase function reads a stale HitRecord.tang");
+        if (mat_needs_tex0(mt) && s->mat_tex0[s->med_mat[m]] < s->n_textures && s->tex_type[s->mat_tex0[s->med_mat[m]]] == RT_TEX_IMAGE)
+            return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: an image texture on a medium reads a stale HitRecord.uv");
+    }
+    for (uint32_t i = 0; i < s->n_spheres && s->sph_medium; ++i)
+        if (s->sph_medium[i] != RT_NO_MEDIUM && s->sph_medium[i] >= s->n_media) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad sphere medium tag");
+    for (uint32_t i = 0; i < s->n_rects && s->rect_medium; ++i)
+        if (s->rect_medium[i] != RT_NO_MEDIUM && s->rect_medium[i] >= s->n_media) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad rectangle medium tag");
     if (s->n_rects && (!s->rect_axis || !s->rect_min || !s->rect_max || !s->rect_mat))
         return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: rectangle arrays missing");
     for (uint32_t i = 0; i < s->n_rects; ++i) {
@@ -373,20 +388,53 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
             }
         }
     }
+    // media: boundary primitive lists; world entries = primitives that are not a boundary, then the media
+    const uint32_t n_entries = n_prims + s->n_media;
+    std::vector<uint32_t> pmed(n_prims, RT_NO_MEDIUM), med_prims;
+    std::vector<uint2> med_range(s->n_media);
+    std::vector<float> med_nid(s->n_media);
+    for (uint32_t i = 0; i < n_prims; ++i)
+        pmed[i] = i < s->n_spheres ? (s->sph_medium ? s->sph_medium[i] : RT_NO_MEDIUM)
+                                   : (s->rect_medium ? s->rect_medium[i - s->n_spheres] : RT_NO_MEDIUM);
+    std::vector<PrimBox> eboxes;
+    std::vector<uint32_t> entry_ids;
+    for (uint32_t i = 0; i < n_prims; ++i)
+        if (pmed[i] == RT_NO_MEDIUM) eboxes.push_back(pboxes[i]), entry_ids.push_back(i);
+    for (uint32_t m = 0; m < s->n_media; ++m) {
+        med_range[m] = make_uint2((uint32_t)med_prims.size(), 0u);
+        med_nid[m] = s->med_neg_inv_density[m];
+        PrimBox mb;
+        for (int k = 0; k < 3; ++k) mb.mn[k] = FLT_MAX, mb.mx[k] = -FLT_MAX;
+        for (uint32_t i = 0; i < n_prims; ++i)
+            if (pmed[i] == m) {
+                med_prims.push_back(i);
+                ++med_range[m].y;
+                for (int k = 0; k < 3; ++k) mb.mn[k] = std::min(mb.mn[k], pboxes[i].mn[k]), mb.mx[k] = std::max(mb.mx[k], pboxes[i].mx[k]);
+            }
+        if (med_range[m].y == 0) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: medium " + std::to_string(m) + " has no boundary primitives");
+        eboxes.push_back(mb);
+        entry_ids.push_back(n_prims + m);
+    }
     HostBvh bvh;
-    build_prim_bvh(pboxes, RT_BVH_MAX_DEPTH, bvh);
-    std::vector<uint8_t> sclass(n_prims);
-    std::vector<float4> srec((size_t)n_prims * 5);
-    for (uint32_t i = 0; i < n_prims; ++i) {
-        const bool is_rect = i >= s->n_spheres;
-        const uint32_t m = is_rect ? s->rect_mat[i - s->n_spheres] : s->sph_mat[i], ty = s->mat_type[m];
+    build_prim_bvh(eboxes, RT_BVH_MAX_DEPTH, bvh);
+    for (auto& dd : bvh.d) { // leaf ids: index into eboxes -> world entry id
+        if (dd.x < 0 && dd.x != INT_MIN) dd.x = ~(int)entry_ids[(size_t)~dd.x];
+        if (dd.y < 0 && dd.y != INT_MIN) dd.y = ~(int)entry_ids[(size_t)~dd.y];
+    }
+    std::vector<uint8_t> sclass(n_entries);
+    std::vector<float4> srec((size_t)n_entries * 5);
+    for (uint32_t i = 0; i < n_entries; ++i) {
+        const bool is_med = i >= n_prims;
+        const bool is_rect = !is_med && i >= s->n_spheres;
+        const uint32_t m = is_med ? s->med_mat[i - n_prims] : (is_rect ? s->rect_mat[i - s->n_spheres] : s->sph_mat[i]);
+        const uint32_t ty = s->mat_type[m];
         const bool has_t0 = mat_needs_tex0(ty) && s->mat_tex0[m] < s->n_textures;
         const uint32_t t0 = has_t0 ? s->mat_tex0[m] : 0u;
         const uint32_t tt = has_t0 ? s->tex_type[t0] : 0u;
         sclass[i] = (uint8_t)(1u + ty * 4u + tt); // < RT_NCLASS
         // colour slot: the texture's colour 0 for textured materials, the albedo for Metal
         const float* col = has_t0 ? s->tex_color0 + 3 * (size_t)t0 : s->mat_color + 3 * (size_t)m;
-        srec[5 * (size_t)i + 0] = is_rect ? rgeo[2 * (size_t)(i - s->n_spheres)] : geo[i];
+        srec[5 * (size_t)i + 0] = is_med ? make_float4(0.f, 0.f, 0.f, 1.f) : (is_rect ? rgeo[2 * (size_t)(i - s->n_spheres)] : geo[i]);
         srec[5 * (size_t)i + 1] = make_float4(fbits(ty), fbits(tt), fbits(has_t0 ? s->tex_aux[t0] : 0u), fbits(s->mat_tex1[m]));
         srec[5 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], s->mat_p0[m]);
         srec[5 * (size_t)i + 3] = make_float4(s->mat_p1[m], s->mat_p2[m], has_t0 ? s->tex_scale[t0] : 0.0f, fbits(s->mat_tex0[m]));
@@ -400,6 +448,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     free_scene(ctx);
     DevScene ds{};
     ds.n_xforms = s->n_xforms;
+    ds.n_media = s->n_media;
     ds.n_rects = s->n_rects;
     ds.n_prims = n_prims;
     ds.n_bvh4_nodes = (uint32_t)bvh4.id.size();
@@ -407,10 +456,13 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     ds.n_spheres = s->n_spheres, ds.n_materials = s->n_materials, ds.n_textures = s->n_textures;
     ds.n_perlin = s->n_perlin, ds.n_images = s->n_images, ds.sky_type = s->sky_type, ds.sky_image = s->sky_image;
     int rc;
-    if ((rc = upload(ctx, geo, &ds.sph_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
+    std::vector<float4> pgeo(geo);
+    pgeo.insert(pgeo.end(), rgeo.begin(), rgeo.end());
+    if ((rc = upload(ctx, pgeo, &ds.prim_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
         (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
-        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, rgeo, &ds.rect_geo)) || (rc = upload(ctx, pxf, &ds.prim_xform)) || (rc = upload(ctx, xparam, &ds.xf_param)) ||
+        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, pmed, &ds.prim_medium)) || (rc = upload(ctx, med_prims, &ds.med_prims)) || (rc = upload(ctx, med_range, &ds.med_range)) ||
+        (rc = upload(ctx, med_nid, &ds.med_neg_inv_density)) || (rc = upload(ctx, pxf, &ds.prim_xform)) || (rc = upload(ctx, xparam, &ds.xf_param)) ||
         (rc = upload(ctx, xmeta, &ds.xf_meta)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
         (rc = upload(ctx, bvh4.p[0], &ds.bvh4_p[0])) || (rc = upload(ctx, bvh4.p[1], &ds.bvh4_p[1])) ||
         (rc = upload(ctx, bvh4.p[2], &ds.bvh4_p[2])) || (rc = upload(ctx, bvh4.p[3], &ds.bvh4_p[3])) ||
@@ -418,11 +470,13 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         free_scene(ctx);
         return rc;
     }
+    ds.sph_geo = ds.prim_geo;
+    ds.rect_geo = ds.prim_geo + s->n_spheres;
     ctx->ds = ds;
     ctx->has_scene = true;
     // k_intersect keeps nodes + spheres + one u16 stack column per lane in LDS
     ctx->isect_lds = bvh_lds_bytes(ds, RT_BVH_BLOCK);
-    ctx->use_bvh = ds.n_prims > 0 && ds.n_bvh4_nodes > 0 && ds.n_bvh4_nodes < 32768 && ds.n_prims <= 32768 &&
+    ctx->use_bvh = ds.n_prims > 0 && ds.n_bvh4_nodes > 0 && ds.n_bvh4_nodes < 32768 && n_entries <= 32768 &&
                    bvh.depth <= RT_BVH_MAX_DEPTH && ctx->isect_lds <= ctx->lds_limit;
     if (ctx->use_bvh) {
         const void* isect_variants[4] = {reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, false>),
@@ -521,7 +575,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
 
     const size_t list_lds = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
     const bool perlin_lds = ctx->ds.n_perlin > 0 && ctx->ds.n_perlin <= RT_PERLIN_LDS_MAX_SETS;
-    const size_t shade_lds = shade_lds_bytes(ctx->ds.n_prims, perlin_lds ? ctx->ds.n_perlin : 0u);
+    const size_t shade_lds = shade_lds_bytes(ctx->ds.n_prims + ctx->ds.n_media, perlin_lds ? ctx->ds.n_perlin : 0u);
     if (shade_lds > 64u * 1024u) return fail(ctx, RT_ERR_UNSUPPORTED, "render: scene has too many spheres for the k_shade class table");
 
     RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
@@ -550,9 +604,9 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             ctx->depth_events.push_back(ev);
         }
     }
-    const IntersectParams ip{nq, cap};
+    IntersectParams ip{nq, cap, 0};
     // selects the "general scene" kernel instantiations (rectangles and Translate / RotateY wrappers)
-    const bool rects = ctx->ds.n_rects > 0 || ctx->ds.n_xforms > 0;
+    const bool rects = ctx->ds.n_rects > 0 || ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0;
     for (uint32_t sl = 0; sl < n_slices; ++sl) {
         const uint32_t s0 = sl * S;
         const uint32_t sc = std::min(S, spp - s0);
@@ -570,16 +624,17 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             const bool td = time_depths && sl == 0;
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth], st));
             const bool gen = fuse_gen && depth == 0;
+            ip.depth = depth;
 #define RT_LAUNCH_ISECT(G, R)                                                                                          \
     hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, \
-                       qi.a, qi.b, qhit, cin, ip, gpd)
+                       qi.a, qi.b, qi.c, qhit, cin, ip, gpd)
             if (use_bvh && gen && rects) RT_LAUNCH_ISECT(true, true);
             else if (use_bvh && gen) RT_LAUNCH_ISECT(true, false);
             else if (use_bvh && rects) RT_LAUNCH_ISECT(false, true);
             else if (use_bvh) RT_LAUNCH_ISECT(false, false);
 #undef RT_LAUNCH_ISECT
             else
-                hipLaunchKernelGGL(k_intersect_list, dim3(nq), dim3(256), list_lds, st, ctx->ds, qi.a, qi.b, qhit, cin, ip);
+                hipLaunchKernelGGL(k_intersect_list, dim3(nq), dim3(256), list_lds, st, ctx->ds, qi.a, qi.b, qi.c, qhit, cin, ip);
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth + 1], st));
             // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
             const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u,

@@ -179,9 +179,17 @@ struct DevScene {
     const float4* xf_param;
     const uint2* xf_meta;
     const uint32_t* prim_xform; // [n_prims] innermost wrapper of the primitive or RT_NO_XFORM_DEV
+    // homogeneous media (hitable.rs:523-588): medium m is world entry n_prims + m; its boundary is the list of
+    // primitives med_prims[med_range[m].x .. +.y), which are not hit directly (prim_medium != RT_NO_XFORM_DEV)
+    uint32_t n_media;
+    const float* med_neg_inv_density;
+    const uint2* med_range;
+    const uint32_t* med_prims;
+    const uint32_t* prim_medium; // [n_prims] owning medium or 0xFFFFFFFF
     uint32_t n_rects;   // axis-aligned rectangles; primitive index = n_spheres + rect index
     uint32_t n_prims;   // n_spheres + n_rects
     const float4* rect_geo; // 2 per rect: (k, u0, u1, v0), (v1, axis bits, 0, 0); (u, v) = uv axes of the rect
+    const float4* prim_geo; // sph_geo[0..n_spheres) followed by rect_geo (one allocation; the LDS image of k_intersect)
     uint32_t n_spheres;
     uint32_t n_materials;
     uint32_t n_textures;
@@ -488,14 +496,15 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     }
     const float4* rec = sc.sph_rec + 5u * (uint32_t)hit;
     const float4 g = rec[0], r1 = rec[1];
-    const bool is_rect = RECTS && (uint32_t)hit >= sc.n_spheres;
+    const bool is_medium = RECTS && (uint32_t)hit >= sc.n_prims;
+    const bool is_rect = RECTS && !is_medium && (uint32_t)hit >= sc.n_spheres;
     // RECTS also stands for "general scene": the primitive may sit below Translate / RotateY wrappers.  The
     // HitRecord is then built from the innermost (object-space) ray and fixed on the way out (hitable.rs:412-414,
     // 494-506); `ro`/`rd` stay the world ray that scatter() receives (main.rs:48).
     Chain chain;
     chain.n = 0;
     V3 wo = ro, wd = rd; // the world ray
-    if (RECTS) {
+    if (RECTS && !is_medium) {
         chain = load_chain(sc, sc.prim_xform[hit]);
         chain_to_object(sc, chain, ro, rd);
     }
@@ -509,10 +518,12 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         const float pv = axis == 2u ? p.y : p.z;
         rect_uv = V2{(pu - g.y) / (g.z - g.y), (pv - g.w) / (g1.x - g.w)};
         on = v3(axis == 0u ? 1.0f : 0.0f, axis == 1u ? 1.0f : 0.0f, axis == 2u ? 1.0f : 0.0f);
+    } else if (is_medium) {
+        on = v3(1.0f, 0.0f, 0.0f);                      // hitable.rs:574 rec.norm = Vec3A::X
     } else {
         on = (p - v3(g.x, g.y, g.z)) / g.w;             // hitable.rs:95 outward_normal
     }
-    bool front_face = dot(rd, on) < 0.0f;               // hitable.rs:26
+    bool front_face = is_medium ? true : dot(rd, on) < 0.0f; // hitable.rs:26 / hitable.rs:575
     V3 n = front_face ? on : -on;                       // hitable.rs:27-31
     if (RECTS && chain.n > 0) {
         // unwind the wrappers from the inside out

@@ -131,10 +131,65 @@ __device__ __forceinline__ void closest_hit_tile(const float4* s_geo, uint32_t n
     }
 }
 
-// The rectangles of the list walk (they follow the spheres in the tie order), read from HBM.
-__device__ __forceinline__ void closest_hit_rects(const DevScene& sc, V3 o, V3 d, float& tbest, int& hit) {
+// Per-ray data a ConstantMedium needs inside hit(): the path's RNG key and the depth's counter block.
+struct MediumCtx {
+    uint32_t k0, k1, base;
+};
+// Candidate root of one geometric primitive through its wrapper chain (general scenes), geometry from `geo`
+// (spheres, then 2 float4 per rectangle; LDS in k_intersect, HBM in the list walk).
+__device__ __forceinline__ bool prim_root(const DevScene& sc, const float4* geo, uint32_t s, V3 o, V3 d, float t_min,
+                                          float t_max, float& th) {
+    const uint32_t xf = sc.prim_xform[s];
+    if (xf != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, xf), o, d);
+    if (s < sc.n_spheres) return sphere_root(geo[s], o, d, length_squared(d), t_min, t_max, th);
+    const uint32_t gi = sc.n_spheres + 2u * (s - sc.n_spheres);
+    return rect_root(geo[gi], geo[gi + 1u], o, d, t_min, t_max, th);
+}
+// boundary.hit(r, t_min, t_max): closest accepted root over the medium's boundary primitives
+__device__ __forceinline__ bool boundary_root(const DevScene& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
+                                              float t_max, float& t_out) {
+    const uint2 rg = sc.med_range[m];
+    bool any = false;
+    for (uint32_t k = 0; k < rg.y; ++k) {
+        float th;
+        if (prim_root(sc, geo, sc.med_prims[rg.x + k], o, d, t_min, t_max, th)) {
+            t_max = th;
+            any = true;
+        }
+    }
+    t_out = t_max;
+    return any;
+}
+// ConstantMedium::hit, hitable.rs:536-579, up to the accepted t.  The random draw is counter slot
+// 224 + m of the depth block (DESIGN.md "RNG"): independent of the order in which media are visited.
+// t_max clamps like the reference's (hitable.rs:553-555); callers pass FLT_MAX and apply the
+// order-independent winner rule, which differs from the clamp only by rounding at exact ties.
+__device__ __forceinline__ bool medium_root(const DevScene& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
+                                            float t_max, const MediumCtx& mc, float& t_hit) {
+    float t1, t2;
+    if (!boundary_root(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
+    if (!boundary_root(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0f) t1 = 0.0f;
+    const float ray_len = length(d);
+    const float dist_inside_boundary = (t2 - t1) * ray_len;
+    const uint32_t r = fmix32(fmix32(mc.k0 ^ ((mc.base + 224u + m) * 0x9E3779B9u)) + mc.k1);
+    const float xi = (float)(r >> 8) * (1.0f / 16777216.0f);
+    const float hit_dist = sc.med_neg_inv_density[m] * logf(xi);
+    if (hit_dist > dist_inside_boundary) return false;
+    t_hit = t1 + hit_dist / ray_len;
+    return true;
+}
+
+// The rectangles and media of the list walk (they follow the spheres in the tie order), read from HBM.
+// Primitives that only bound a medium are skipped (hitable.rs:523-533: the boundary lives inside the medium).
+__device__ __forceinline__ void closest_hit_rects(const DevScene& sc, V3 o, V3 d, const MediumCtx& mc, float& tbest,
+                                                  int& hit) {
     for (uint32_t r = 0; r < sc.n_rects; ++r) {
         float th;
+        if (sc.prim_medium[sc.n_spheres + r] != RT_NO_XFORM_DEV) continue;
         V3 po = o, pd = d;
         const uint32_t xf = sc.prim_xform[sc.n_spheres + r];
         if (xf != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, xf), po, pd);
@@ -143,11 +198,19 @@ __device__ __forceinline__ void closest_hit_rects(const DevScene& sc, V3 o, V3 d
             hit = (int)(sc.n_spheres + r);
         }
     }
+    for (uint32_t m = 0; m < sc.n_media; ++m) {
+        float th;
+        if (medium_root(sc, sc.prim_geo, m, o, d, 1e-3f, tbest, mc, th)) {
+            tbest = th;
+            hit = (int)(sc.n_prims + m);
+        }
+    }
 }
 // List walk over spheres of a scene with wrappers (read from HBM; the LDS tile loop assumes none).
 __device__ __forceinline__ void closest_hit_spheres_general(const DevScene& sc, V3 o, V3 d, float& tbest, int& hit) {
     for (uint32_t s = 0; s < sc.n_spheres; ++s) {
         float th;
+        if (sc.prim_medium[s] != RT_NO_XFORM_DEV) continue;
         V3 po = o, pd = d;
         const uint32_t xf = sc.prim_xform[s];
         if (xf != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, xf), po, pd);
@@ -227,7 +290,8 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
 // relative widening that covers the rounding of inv and of the fma itself.
 template <int BLOCK, bool RECTS>
 __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float nox, float noy,
-                                         float noz, float eps, float a, int& cur, int& sp, float& tbest, int& hit) {
+                                         float noz, float eps, float a, const MediumCtx& mc, int& cur, int& sp,
+                                         float& tbest, int& hit) {
     if (cur >= 0) {
         const float4 mnx = L.pl[0][cur], mny = L.pl[1][cur], mnz = L.pl[2][cur];
         const float4 mxx = L.pl[3][cur], mxy = L.pl[4][cur], mxz = L.pl[5][cur];
@@ -273,20 +337,12 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
         if (!RECTS) {
             ok = sphere_root(L.geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th);
         } else {
-            // general scene: the primitive may sit below Translate / RotateY wrappers (t is unchanged by them)
-            V3 po = o, pd = d;
-            float pa = a;
-            const uint32_t xf = L.sc->prim_xform[s];
-            if (xf != RT_NO_XFORM_DEV) {
-                chain_to_object(*L.sc, load_chain(*L.sc, xf), po, pd);
-                pa = length_squared(pd); // hitable.rs:77 on the rotated direction
-            }
-            if ((uint32_t)s < L.n_spheres) {
-                ok = sphere_root(L.geo[s], po, pd, pa, 1e-3f, RT_FLT_MAX, th);
-            } else {
-                const uint32_t gi = L.n_spheres + 2u * ((uint32_t)s - L.n_spheres);
-                ok = rect_root(L.geo[gi], L.geo[gi + 1u], po, pd, 1e-3f, RT_FLT_MAX, th);
-            }
+            // general scene: a medium, or a primitive that may sit below Translate / RotateY wrappers (t is
+            // unchanged by them)
+            if ((uint32_t)s >= L.sc->n_prims)
+                ok = medium_root(*L.sc, L.geo, (uint32_t)s - L.sc->n_prims, o, d, 1e-3f, RT_FLT_MAX, mc, th);
+            else
+                ok = prim_root(*L.sc, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
         }
         if (ok && (th < tbest || (th == tbest && s > hit))) {
             tbest = th;
@@ -300,6 +356,7 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
 }
 struct IntersectParams {
     uint32_t nq, cap;
+    int depth;
 };
 
 // Closest hit for every queued ray of the shards q = blockIdx.x, blockIdx.x + gridDim.x, ...
@@ -311,9 +368,9 @@ struct IntersectParams {
 // GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
 template <int BLOCK, bool GEN, bool RECTS>
 __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* __restrict__ qa,
-                                                     const float4* __restrict__ qb, float2* __restrict__ qh,
-                                                     const uint32_t* __restrict__ in_counts, IntersectParams ip,
-                                                     const GenParams* __restrict__ gpd) {
+                                                     const float4* __restrict__ qb, const float4* __restrict__ qc,
+                                                     float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
+                                                     IntersectParams ip, const GenParams* __restrict__ gpd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // virtual index space over this workgroup's shards (at most RT_ISECT_MAX_SHARDS, host-checked)
     uint32_t pre[RT_ISECT_MAX_SHARDS + 1];
@@ -340,6 +397,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
     float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, eps = 0.f, a = 1.0f, tbest = RT_FLT_MAX;
     int hit = -1, cur = 0, sp = 0;
     size_t pos = 0;
+    MediumCtx mc{0u, 0u, depth_counter_base(ip.depth)};
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -362,10 +420,12 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
                 if (GEN) {
                     uint32_t k0, k1;
                     gen_primary(*gpd, primary_idx_of(ip.nq, shard, off), o, d, k0, k1);
+                    if (RECTS) mc.k0 = k0, mc.k1 = k1;
                 } else {
                     const float4 ra = qa[pos], rb = qb[pos];
                     o = v3(ra.x, ra.y, ra.z);
                     d = v3(rb.x, rb.y, rb.z);
+                    if (RECTS && sc.n_media) mc.k0 = __float_as_uint(rb.w), mc.k1 = __float_as_uint(qc[pos].w);
                 }
                 ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
                 nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
@@ -383,7 +443,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
             if (exhausted) break;
             continue;
         }
-        if (has && bvh_step<BLOCK, RECTS>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, cur, sp, tbest, hit)) {
+        if (has && bvh_step<BLOCK, RECTS>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, mc, cur, sp, tbest, hit)) {
             qh[pos] = make_float2(tbest, __int_as_float(hit));
             has = false;
         }
@@ -392,8 +452,9 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
 
 // List-walk closest hit: one workgroup per shard, sphere list streamed through LDS tiles.
 __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float4* __restrict__ qa,
-                                                        const float4* __restrict__ qb, float2* __restrict__ qh,
-                                                        const uint32_t* __restrict__ in_counts, IntersectParams ip) {
+                                                        const float4* __restrict__ qb, const float4* __restrict__ qc,
+                                                        float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
+                                                        IntersectParams ip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_geo = reinterpret_cast<float4*>(smem);
     const uint32_t q = blockIdx.x;
@@ -418,7 +479,7 @@ __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float
         float tbest = RT_FLT_MAX;
         int hit = -1;
         const float a = length_squared(d);
-        if (sc.n_xforms) {
+        if (sc.n_xforms || sc.n_media) {
             closest_hit_spheres_general(sc, o, d, tbest, hit);
         } else if (single_tile) {
             closest_hit_tile(s_geo, n_sph, 0u, o, d, a, tbest, hit);
@@ -431,7 +492,9 @@ __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float
                 closest_hit_tile(s_geo, n, t0, o, d, a, tbest, hit);
             }
         }
-        closest_hit_rects(sc, o, d, tbest, hit);
+        MediumCtx mc{0u, 0u, depth_counter_base(ip.depth)};
+        if (active && sc.n_media) mc.k0 = __float_as_uint(qb[qbase + i].w), mc.k1 = __float_as_uint(qc[qbase + i].w);
+        closest_hit_rects(sc, o, d, mc, tbest, hit);
         if (active) qh[qbase + i] = make_float2(tbest, __int_as_float(hit));
     }
 }
@@ -480,8 +543,8 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
     uint32_t* s_offs = s_hist + RT_NCLASS;
     unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_offs + RT_NCLASS);
     uint8_t* s_class = reinterpret_cast<uint8_t*>(s_perm + RT_SORT_N);
-    const uint32_t class_bytes = (sc.n_prims + 15u) & ~15u;
-    for (uint32_t i = threadIdx.x; i < sc.n_prims; i += 256u) s_class[i] = sc.sph_class[i];
+    const uint32_t class_bytes = (sc.n_prims + sc.n_media + 15u) & ~15u;
+    for (uint32_t i = threadIdx.x; i < sc.n_prims + sc.n_media; i += 256u) s_class[i] = sc.sph_class[i];
     PerlinTables pt{sc.perlin_vec, sc.perlin_perm};
     if (PERLIN_LDS) {
         float4* lv = reinterpret_cast<float4*>(s_class + class_bytes);
@@ -689,12 +752,13 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
             const float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
             const float eps = 2.4e-7f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
             int cur = 0, sp = 0;
-            while (!bvh_step<BLOCK, true>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, cur, sp, tbest, hit)) {
+            const MediumCtx mc{active ? in_key[2 * i] : 0u, active ? in_key[2 * i + 1] : 0u, depth_counter_base(depth)};
+            while (!bvh_step<BLOCK, true>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, mc, cur, sp, tbest, hit)) {
             }
         }
     } else {
         float4* s_geo = reinterpret_cast<float4*>(smem);
-        if (sc.n_xforms) {
+        if (sc.n_xforms || sc.n_media) {
             closest_hit_spheres_general(sc, o, d, tbest, hit);
         } else {
             for (uint32_t t0 = 0; t0 < sc.n_spheres; t0 += RT_SPHERE_TILE) {
@@ -705,7 +769,8 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
                 closest_hit_tile(s_geo, nn, t0, o, d, a, tbest, hit);
             }
         }
-        closest_hit_rects(sc, o, d, tbest, hit);
+        const MediumCtx mc{active ? in_key[2 * i] : 0u, active ? in_key[2 * i + 1] : 0u, depth_counter_base(depth)};
+        closest_hit_rects(sc, o, d, mc, tbest, hit);
     }
     if (!active) return;
     uint32_t n_fetch = 0;

@@ -1,8 +1,8 @@
 // demo_scene.cpp — host-side mirror of the reference scene builders that feed the accelerated
 // path (demo_scene.rs:37-86 sphere_scene, demo_scene.rs:229-244 test_sphere) plus the two
 // build-authored scenes BASELINE.json configs 4 and 5 call for.  The other three reference
-// scenes: simple_light_scene (spheres + an XYRect) is mirrored below; cornell_box and final_scene need
-// instance transforms and ConstantMedium, which are not on the accelerated path yet.
+// scenes: simple_light_scene (spheres + an XYRect) and cornell_box (rectangles, RotateY/Translate boxes that bound
+// two ConstantMedium) are mirrored below; final_scene (1000-sphere and 400-box sub-BVHs) is not yet.
 #include "rtow.hpp"
 
 #include <cstdio>
@@ -121,6 +121,35 @@ std::pair<HitableList, Camera> simple_light_scene(float aspect_ratio) {
     };
     Camera cam = Camera::new_(vec3a(26.0f, 3.0f, 6.0f), vec3a(0.0f, 0.0f, 0.0f), vec3a(0.0f, 1.0f, 0.0f), 20.0f, aspect_ratio);
     return build_bvh(world, cam); // :109
+}
+
+// demo_scene.rs:112-148 — Cornell box; the two boxes only bound the black and the white smoke.
+std::pair<HitableList, Camera> cornell_box(float aspect_ratio) {
+    SKY_COLOR_set(SkyFn::black_sky); // :113
+    auto red = std::make_shared<Diffuse>(std::make_shared<ConstantTex>(vec3a(0.65f, 0.05f, 0.05f)));
+    auto white = std::make_shared<Diffuse>(std::make_shared<ConstantTex>(vec3a(0.73f, 0.73f, 0.73f)));
+    auto green = std::make_shared<Diffuse>(std::make_shared<ConstantTex>(vec3a(0.12f, 0.45f, 0.15f)));
+    auto light = std::make_shared<Emission>(std::make_shared<ConstantTex>(vec3a(7.0f, 7.0f, 7.0f)));
+    HitablePtr box_1 = GBox::new_(Vec3A::ZERO(), vec3a(165.0f, 330.0f, 165.0f), white);
+    box_1 = RotateY::new_(box_1, 15.0f);
+    box_1 = std::make_shared<Translate>(vec3a(265.0f, 0.0f, 295.0f), box_1);
+    auto mediun_1 = ConstantMedium::new_(box_1, 0.01f, std::make_shared<ConstantTex>(Vec3A::ZERO()));
+    HitablePtr box_2 = GBox::new_(Vec3A::ZERO(), vec3a(165.0f, 165.0f, 165.0f), white);
+    box_2 = RotateY::new_(box_2, -18.0f);
+    box_2 = std::make_shared<Translate>(vec3a(130.0f, 0.0f, 65.0f), box_2);
+    auto mediun_2 = ConstantMedium::new_(box_2, 0.01f, std::make_shared<ConstantTex>(Vec3A::ONE()));
+    HitableList world = {
+        std::make_shared<XZRect>(vec3a(113.0f, 554.0f, 127.0f), vec3a(443.0f, 554.0f, 432.0f), light),
+        std::make_shared<XYRect>(vec3a(0.0f, 0.0f, 555.0f), vec3a(555.0f, 555.0f, 555.0f), white),
+        std::make_shared<XZRect>(vec3a(0.0f, 0.0f, 0.0f), vec3a(555.0f, 0.0f, 555.0f), white),
+        std::make_shared<XZRect>(vec3a(0.0f, 555.0f, 0.0f), vec3a(555.0f, 555.0f, 555.0f), white),
+        std::make_shared<YZRect>(vec3a(0.0f, 0.0f, 0.0f), vec3a(0.0f, 555.0f, 555.0f), red),
+        std::make_shared<YZRect>(vec3a(555.0f, 0.0f, 0.0f), vec3a(555.0f, 555.0f, 555.0f), green),
+        mediun_1,
+        mediun_2,
+    };
+    Camera cam = Camera::new_(vec3a(278.0f, 278.0f, -800.0f), vec3a(278.0f, 278.0f, 0.0f), vec3a(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio);
+    return build_bvh(world, cam); // :147
 }
 
 // BASELINE.json config 4: earthmap-textured sphere under the newport_loft environment sky.

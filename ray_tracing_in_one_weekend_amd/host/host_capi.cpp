@@ -83,6 +83,7 @@ int rth_scene_build(const char* name, float aspect_ratio, RthScene** out) {
         if (n == "sphere_scene") fn = sphere_scene;
         else if (n == "test_sphere") fn = test_sphere;
         else if (n == "simple_light_scene") fn = simple_light_scene;
+        else if (n == "cornell_box") fn = cornell_box;
         else if (n == "earth_env_scene") fn = earth_env_scene;
         else if (n == "pbr_sweep_scene") fn = pbr_sweep_scene;
         else throw std::runtime_error("rth_scene_build: unknown scene '" + n + "'");
@@ -205,6 +206,15 @@ uint32_t rth_rotate_y(RthScene* s, uint32_t hitable, float angle_degrees) {
     return guarded_handle([&]() -> uint32_t {
         if (hitable >= s->world.size()) throw std::runtime_error("rth_rotate_y: bad hitable handle");
         s->world[hitable] = RotateY::new_(s->world[hitable], angle_degrees);
+        return hitable;
+    });
+}
+
+// Replaces world entry `hitable` by ConstantMedium::new(hitable, density, phase texture) (hitable.rs:529-533).
+uint32_t rth_constant_medium(RthScene* s, uint32_t hitable, float density, uint32_t phase_tex) {
+    return guarded_handle([&]() -> uint32_t {
+        if (hitable >= s->world.size()) throw std::runtime_error("rth_constant_medium: bad hitable handle");
+        s->world[hitable] = ConstantMedium::new_(s->world[hitable], density, get_tex(s, phase_tex, "ConstantMedium.phase_fn"));
         return hitable;
     });
 }

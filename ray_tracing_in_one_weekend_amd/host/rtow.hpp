@@ -5,6 +5,7 @@
 //   Sphere{c, r, mat, name}                                    hitable.rs:57-62
 //   XYRect/XZRect/YZRect{min, max, mat}, GBox::new_(min,max,mat)  hitable.rs:244-402
 //   Translate{offset, ptr}, RotateY::new_(ptr, angle)          hitable.rs:404-520
+//   ConstantMedium::new_(boundary, density, phase_tex)         hitable.rs:523-588
 //   HitableList = vector<shared_ptr<Hitable>>                  hitable.rs:114
 //   BvhNode::new_(objects, start, end)                         hitable.rs:177-221
 //   Emission{emit} Diffuse{albedo} Lambert{albedo} Metal{albedo,fuzz} Dielectric{ior}
@@ -155,12 +156,24 @@ class FlatSceneBuilder {
         push3(rect_min, mn), push3(rect_max, mx);
         rect_mat.push_back(mat);
         rect_xform.push_back(cur_xform);
+        rect_medium.push_back(cur_medium);
     }
     void push_sphere(Vec3A c, float r, uint32_t mat, const std::string& name) {
         sph_cx.push_back(c.x), sph_cy.push_back(c.y), sph_cz.push_back(c.z), sph_r.push_back(r), sph_mat.push_back(mat);
         sph_name.push_back(name);
         sph_xform.push_back(cur_xform);
+        sph_medium.push_back(cur_medium);
     }
+    // hitable.rs:523-533 ConstantMedium: primitives pushed until end_medium() bound medium `m`
+    uint32_t begin_medium(float neg_inv_density, uint32_t mat) {
+        if (cur_medium != RT_NO_MEDIUM) throw std::runtime_error("flatten: a ConstantMedium inside a ConstantMedium boundary");
+        if (med_mat.size() >= RT_MAX_MEDIA) throw std::runtime_error("flatten: more than RT_MAX_MEDIA media");
+        med_neg_inv_density.push_back(neg_inv_density);
+        med_mat.push_back(mat);
+        cur_medium = (uint32_t)med_mat.size() - 1;
+        return cur_medium;
+    }
+    void end_medium() { cur_medium = RT_NO_MEDIUM; }
     // Opens an instance wrapper (hitable.rs:404-520): primitives pushed until the matching
     // pop_xform() lie below it.  Returns the previous innermost wrapper (to restore).
     uint32_t push_xform(uint8_t type, float p0, float p1, float p2) {
@@ -187,6 +200,9 @@ class FlatSceneBuilder {
         s.n_xforms = (uint32_t)xf_type.size();
         s.xf_type = xf_type.data(), s.xf_param = xf_param.data(), s.xf_parent = xf_parent.data();
         s.sph_xform = sph_xform.data(), s.rect_xform = rect_xform.data();
+        s.n_media = (uint32_t)med_mat.size();
+        s.med_neg_inv_density = med_neg_inv_density.data(), s.med_mat = med_mat.data();
+        s.sph_medium = sph_medium.data(), s.rect_medium = rect_medium.data();
         s.n_materials = (uint32_t)mat_type.size();
         s.mat_type = mat_type.data(), s.mat_color = mat_color.data();
         s.mat_p0 = mat_p0.data(), s.mat_p1 = mat_p1.data(), s.mat_p2 = mat_p2.data(), s.mat_p3 = mat_p3.data();
@@ -213,6 +229,9 @@ class FlatSceneBuilder {
     std::vector<float> xf_param;
     std::vector<uint32_t> xf_parent, sph_xform, rect_xform;
     uint32_t cur_xform = RT_NO_XFORM, xform_depth = 0;
+    std::vector<float> med_neg_inv_density;
+    std::vector<uint32_t> med_mat, sph_medium, rect_medium;
+    uint32_t cur_medium = RT_NO_MEDIUM;
     std::vector<uint8_t> mat_type;
     std::vector<float> mat_color, mat_p0, mat_p1, mat_p2, mat_p3;
     std::vector<uint32_t> mat_tex0, mat_tex1;
@@ -540,6 +559,30 @@ class RotateY : public Hitable {
     float angle_ = 0, sin_theta_ = 0, cos_theta_ = 1;
 };
 
+// hitable.rs:523-588 — ConstantMedium::new(boundary, density, phase_fn_texture); the phase function is
+// Isotropic { albedo } (material.rs:99-113)
+class ConstantMedium : public Hitable {
+  public:
+    static std::shared_ptr<ConstantMedium> new_(HitablePtr boundary, float density, TexturePtr phase_fn) {
+        auto m = std::shared_ptr<ConstantMedium>(new ConstantMedium());
+        m->boundary_ = std::move(boundary);
+        m->phase_fn_ = std::make_shared<Isotropic>(std::move(phase_fn));
+        m->neg_inv_density_ = -1.0f / density;
+        return m;
+    }
+    void flatten(FlatSceneBuilder& b) const override {
+        b.begin_medium(neg_inv_density_, b.intern_material(phase_fn_.get()));
+        boundary_->flatten(b);
+        b.end_medium();
+    }
+    std::string memo() const override { throw std::runtime_error("ConstantMedium::memo: todo!() in the reference (hitable.rs:585-587)"); }
+
+  private:
+    HitablePtr boundary_;
+    MaterialPtr phase_fn_;
+    float neg_inv_density_ = 0;
+};
+
 // hitable.rs:158-221.  The accelerated path does its own closest-hit search, so the mirror
 // keeps the primitives of [start, end) in construction order and replays only the RNG side
 // effect of the reference constructor (one gen_range(0..3) per node, hitable.rs:182-184).
@@ -634,6 +677,7 @@ using SceneFn = std::pair<HitableList, Camera> (*)(float aspect_ratio);
 std::pair<HitableList, Camera> sphere_scene(float aspect_ratio); // demo_scene.rs:37-86  "random-spheres"
 std::pair<HitableList, Camera> test_sphere(float aspect_ratio);  // demo_scene.rs:229-244
 std::pair<HitableList, Camera> simple_light_scene(float aspect_ratio); // demo_scene.rs:88-110 (spheres + XYRect light)
+std::pair<HitableList, Camera> cornell_box(float aspect_ratio);        // demo_scene.rs:112-148 (walls + two smoke boxes)
 // Build-authored scenes from reference constructors (BASELINE.json configs 4 and 5; the
 // reference ships no scene for them).
 std::pair<HitableList, Camera> earth_env_scene(float aspect_ratio);

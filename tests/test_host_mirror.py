@@ -94,7 +94,7 @@ def test_piecewise_construction_and_errors(rt):
     s.finish()
     assert s.flat.n_spheres == 2 and s.flat.n_materials == 1 and s.flat.n_textures == 1
     with pytest.raises(rt.RtError):
-        rt.Scene.build("cornell_box", 1.0)  # rect/box/medium scenes are outside the accelerated path
+        rt.Scene.build("final_scene", 1.0)  # not mirrored yet (1000-sphere and 400-box sub-BVHs)
     s2 = rt.Scene.new()
     with pytest.raises(rt.RtError):
         s2.material(rt._ffi.MAT_DIFFUSE)  # Diffuse needs an albedo texture
@@ -120,3 +120,17 @@ def test_simple_light_scene_and_boxes(rt):
     a = b.arrays()  # GBox::new order: XY(min.z), XY(max.z), XZ(min.y), XZ(max.y), YZ(min.x), YZ(max.x)
     assert a["rect_axis"].tolist() == [2, 2, 1, 1, 0, 0]
     assert a["rect_min"].reshape(6, 3)[[0, 1, 2, 3, 4, 5], [2, 2, 1, 1, 0, 0]].tolist() == [0, 3, 0, 2, 0, 1]
+
+
+def test_cornell_box_mirror(rt):
+    s = rt.Scene.build("cornell_box", 1.0)  # demo_scene.rs:112-148
+    a = s.arrays()
+    assert s.flat.n_spheres == 0 and s.flat.n_rects == 18 and s.flat.n_media == 2 and s.flat.n_xforms == 4
+    assert a["xf_type"].tolist() == [0, 1, 0, 1] and a["xf_param"].reshape(4, 4)[0, :3].tolist() == [265.0, 0.0, 295.0]
+    assert a["xf_param"].reshape(4, 4)[1, 2] == 15.0 and a["xf_param"].reshape(4, 4)[3, 2] == -18.0
+    assert a["rect_xform"].tolist() == [rt._ffi.NO_XFORM] * 6 + [1] * 6 + [3] * 6
+    assert a["med_neg_inv_density"].tolist() == [-100.0, -100.0]  # -1 / 0.01
+    assert [a["mat_type"][m] for m in a["med_mat"]] == [rt._ffi.MAT_ISOTROPIC] * 2
+    # phase textures: black smoke, white smoke (demo_scene.rs:123,128)
+    t0, t1 = a["mat_tex0"][a["med_mat"][0]], a["mat_tex0"][a["med_mat"][1]]
+    assert a["tex_color0"][3 * t0:3 * t0 + 3].tolist() == [0, 0, 0] and a["tex_color0"][3 * t1:3 * t1 + 3].tolist() == [1, 1, 1]

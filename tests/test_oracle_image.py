@@ -146,3 +146,16 @@ def test_simple_light_scene_oracle(rt, orc):
     assert a.max() <= 4.0 + 1e-5 and a.max() == 4.0 and a.min() == 0.0  # emitters are (4,4,4), seen directly somewhere
     c, _, sc = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_STREAM))
     assert abs(a.mean() - c.mean()) / a.mean() < 0.05
+
+
+def test_cornell_box_oracle(rt, orc):
+    """demo_scene.rs:112-148 with the smoke boxes: list walk, BVH and reference-order stream agree statistically
+    (the medium's draw order differs between them only in stream mode)."""
+    scene = rt.Scene.build("cornell_box", 1.0)
+    p = rt.make_params(96, 96, 32, max_depth=50)
+    a, _, sa = orc.render(scene.flat_ptr, scene.camera, p, orc.options(accel=orc.ACCEL_LIST))
+    b, _, sb = orc.render(scene.flat_ptr, scene.camera, p, orc.options(accel=orc.ACCEL_BVH))
+    c, _, sc = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_STREAM))
+    assert abs(int(sa.n_rays) - int(sb.n_rays)) / sa.n_rays < 1e-3 and (np.abs(a - b).max(axis=2) > 1e-4).mean() < 5e-3
+    assert abs(a.mean() - c.mean()) / a.mean() < 0.03 and np.isfinite(a).all()
+    assert a.max() <= 7.0 + 1e-4  # the light is (7,7,7)
