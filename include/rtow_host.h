@@ -39,7 +39,7 @@ int rth_register_image(const char* path, uint32_t w, uint32_t h, const float* rg
 void rth_rng_reseed(uint64_t seed);
 
 /* Runs a named scene function: "sphere_scene", "test_sphere", "simple_light_scene",
- * "cornell_box", "earth_env_scene", "pbr_sweep_scene"; flattens world + sky + camera.  The thread RNG is reset to its
+ * "cornell_box", "final_scene", "earth_env_scene", "pbr_sweep_scene"; flattens world + sky + camera.  The thread RNG is reset to its
  * fresh-process state (seed 1995) first, so repeated builds give identical Perlin tables. */
 int rth_scene_build(const char* name, float aspect_ratio, RthScene** out);
 

@@ -1498,6 +1498,33 @@ void orc_perlin_tables(uint64_t seed, uint32_t n_sets, float* vec_out, uint16_t*
 }
 
 /*
+ * demo_scene.rs:150-221 — the thread-RNG draws of final_scene in source order: PerlinTex::new(0.1) (:164),
+ * 1000 x vec3a_random_range(0., 165.) (:176-178), one gen_range(0..3) per node of BvhNode::new over the 1000
+ * spheres (:179, hitable.rs:177-221: the node itself, then its left half, then its right half), then the 400
+ * box heights gen::<f32>() * 100. + 1. (:192).  Independent restatement of what the host mirror must produce.
+ */
+static void final_scene_bvh_axes(Xoshiro256pp& r, size_t span) {
+    (void)gen_range_u64(r, 0, 3);
+    if (span > 2) {
+        final_scene_bvh_axes(r, span / 2);
+        final_scene_bvh_axes(r, span - span / 2);
+    }
+}
+void orc_final_scene_layout(uint64_t seed, float* centres /* [3000] */, float* heights /* [400] */) {
+    Xoshiro256pp rng = smallrng_seed_from_u64(seed);
+    std::vector<float> vec(768);
+    std::vector<uint16_t> perm(768);
+    perlin_default(rng, vec.data(), perm.data());
+    for (int i = 0; i < 1000; ++i) {
+        float x = rng.next_f32(), y = rng.next_f32(), z = rng.next_f32();
+        V3 c = V3{x, y, z} * (165.0f - 0.0f) + 0.0f;
+        centres[3 * i] = c.x, centres[3 * i + 1] = c.y, centres[3 * i + 2] = c.z;
+    }
+    final_scene_bvh_axes(rng, 1000);
+    for (int i = 0; i < 400; ++i) heights[i] = rng.next_f32() * 100.0f + 1.0f;
+}
+
+/*
  * demo_scene.rs:56-77 — the random-spheres layout drawn from SmallRng::seed_from_u64(95).
  * Emits, for each of the 529 small spheres: center xyz, kind (0 diffuse, 1 metal, 2 glass),
  * colour rgb and fuzz (8 floats per sphere).  The oracle's independent restatement of what the

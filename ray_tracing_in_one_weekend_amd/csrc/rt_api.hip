@@ -48,7 +48,8 @@ struct RtCtx {
     int n_cu = 256;
     size_t lds_limit = 64 * 1024;
     bool use_bvh = false;      // scene BVH fits LDS next to the traversal stacks
-    size_t isect_lds = 0;      // k_intersect: nodes + spheres + bvh_depth levels of stack + counters
+    size_t isect_lds = 0;      // k_intersect: nodes + geometry (when they fit) + stack levels + counters
+    bool bvh_in_lds = false;   // false: the tree is traversed out of HBM/L2, only the stacks are in LDS
 };
 
 namespace {
@@ -474,19 +475,27 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     ds.rect_geo = ds.prim_geo + s->n_spheres;
     ctx->ds = ds;
     ctx->has_scene = true;
-    // k_intersect keeps nodes + spheres + one u16 stack column per lane in LDS
-    ctx->isect_lds = bvh_lds_bytes(ds, RT_BVH_BLOCK);
-    ctx->use_bvh = ds.n_prims > 0 && ds.n_bvh4_nodes > 0 && ds.n_bvh4_nodes < 32768 && n_entries <= 32768 &&
-                   bvh.depth <= RT_BVH_MAX_DEPTH && ctx->isect_lds <= ctx->lds_limit;
+    // k_intersect keeps nodes + geometry + one u16 stack column per lane in LDS when that fits 160 KB;
+    // larger trees are traversed out of HBM/L2 with only the stacks in LDS; the list walk is the last resort
+    const bool bvh_ok = ds.n_prims > 0 && ds.n_bvh4_nodes > 0 && ds.n_bvh4_nodes < 32768 && n_entries <= 32768 &&
+                        bvh.depth <= RT_BVH_MAX_DEPTH;
+    const char* force_hbm = getenv("RTOW_BVH_HBM");   // test hook: traverse out of HBM even when LDS would fit
+    ctx->bvh_in_lds = bvh_ok && bvh_lds_bytes(ds, RT_BVH_BLOCK, true) <= ctx->lds_limit &&
+                      !(force_hbm && force_hbm[0] == '1');
+    ctx->isect_lds = bvh_lds_bytes(ds, RT_BVH_BLOCK, ctx->bvh_in_lds);
+    ctx->use_bvh = bvh_ok && ctx->isect_lds <= ctx->lds_limit;
     if (ctx->use_bvh) {
-        const void* isect_variants[4] = {reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, false>),
-                                         reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true>),
-                                         reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, false>),
-                                         reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true>)};
-        for (const void* fn : isect_variants)
+        const void* variants[] = {
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, false, true>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, true>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, false, true>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, true>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, false>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, false>),
+            reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, true>),
+            reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, false>)};
+        for (const void* fn : variants)
             RT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
-        RT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
     }
     return RT_OK;
 }
@@ -625,13 +634,16 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth], st));
             const bool gen = fuse_gen && depth == 0;
             ip.depth = depth;
-#define RT_LAUNCH_ISECT(G, R)                                                                                          \
-    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, \
+#define RT_LAUNCH_ISECT(G, R, N)                                                                                       \
+    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R, N>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, \
                        qi.a, qi.b, qi.c, qhit, cin, ip, gpd)
-            if (use_bvh && gen && rects) RT_LAUNCH_ISECT(true, true);
-            else if (use_bvh && gen) RT_LAUNCH_ISECT(true, false);
-            else if (use_bvh && rects) RT_LAUNCH_ISECT(false, true);
-            else if (use_bvh) RT_LAUNCH_ISECT(false, false);
+            // trees that do not fit LDS use the general instantiation (R = true works for sphere-only scenes too)
+            if (use_bvh && !ctx->bvh_in_lds && gen) RT_LAUNCH_ISECT(true, true, false);
+            else if (use_bvh && !ctx->bvh_in_lds) RT_LAUNCH_ISECT(false, true, false);
+            else if (use_bvh && gen && rects) RT_LAUNCH_ISECT(true, true, true);
+            else if (use_bvh && gen) RT_LAUNCH_ISECT(true, false, true);
+            else if (use_bvh && rects) RT_LAUNCH_ISECT(false, true, true);
+            else if (use_bvh) RT_LAUNCH_ISECT(false, false, true);
 #undef RT_LAUNCH_ISECT
             else
                 hipLaunchKernelGGL(k_intersect_list, dim3(nq), dim3(256), list_lds, st, ctx->ds, qi.a, qi.b, qi.c, qhit, cin, ip);
@@ -766,14 +778,19 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
     RT_HIP(ctx, hipMemcpyAsync(base + off_d, io->in_d, 3 * n * 4, hipMemcpyHostToDevice, st));
     RT_HIP(ctx, hipMemcpyAsync(base + off_key, io->in_key, 2 * n * 4, hipMemcpyHostToDevice, st));
     const bool use_bvh = ctx->use_bvh && !(io->flags & RT_FLAG_BRUTE_FORCE);
-    if (use_bvh) {
-        hipLaunchKernelGGL((k_debug_bounce<RT_BVH_BLOCK, true>), dim3((unsigned)((n + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK)),
+    if (use_bvh && !ctx->bvh_in_lds) {
+        hipLaunchKernelGGL((k_debug_bounce<RT_BVH_BLOCK, true, false>), dim3((unsigned)((n + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK)),
+                           dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, (uint32_t)n, (int)io->depth, base + off_o, base + off_d,
+                           (const uint32_t*)(base + off_key), (int*)(base + off_hit), base + off_t, base + off_rad, base + off_att,
+                           base + off_so, base + off_sd, (uint8_t*)(base + off_alive));
+    } else if (use_bvh) {
+        hipLaunchKernelGGL((k_debug_bounce<RT_BVH_BLOCK, true, true>), dim3((unsigned)((n + RT_BVH_BLOCK - 1) / RT_BVH_BLOCK)),
                            dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, (uint32_t)n, (int)io->depth, base + off_o, base + off_d,
                            (const uint32_t*)(base + off_key), (int*)(base + off_hit), base + off_t, base + off_rad, base + off_att,
                            base + off_so, base + off_sd, (uint8_t*)(base + off_alive));
     } else {
         const size_t lds_bytes = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
-        hipLaunchKernelGGL((k_debug_bounce<256, false>), dim3((unsigned)((n + 255) / 256)), dim3(256), lds_bytes, st, ctx->ds,
+        hipLaunchKernelGGL((k_debug_bounce<256, false, true>), dim3((unsigned)((n + 255) / 256)), dim3(256), lds_bytes, st, ctx->ds,
                            (uint32_t)n, (int)io->depth, base + off_o, base + off_d, (const uint32_t*)(base + off_key),
                            (int*)(base + off_hit), base + off_t, base + off_rad, base + off_att, base + off_so, base + off_sd,
                            (uint8_t*)(base + off_alive));

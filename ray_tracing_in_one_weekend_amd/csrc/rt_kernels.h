@@ -233,8 +233,8 @@ __device__ __forceinline__ void closest_hit_spheres_general(const DevScene& sc, 
 // node), sphere list (16 B each), the per-lane traversal stack [level][thread] (u16; a node pushes up
 // to 3 children, so 3 levels per tree level), 16 B of counters.
 __host__ __device__ inline uint32_t bvh_stack_levels(const DevScene& sc) { return 3u * (sc.bvh4_depth ? sc.bvh4_depth : 1u) + 1u; }
-__host__ __device__ inline size_t bvh_lds_bytes(const DevScene& sc, uint32_t block) {
-    return (size_t)sc.n_bvh4_nodes * 112u + ((size_t)sc.n_spheres + 2u * sc.n_rects) * 16u +
+__host__ __device__ inline size_t bvh_lds_bytes(const DevScene& sc, uint32_t block, bool lds_nodes = true) {
+    return (lds_nodes ? (size_t)sc.n_bvh4_nodes * 112u + ((size_t)sc.n_spheres + 2u * sc.n_rects) * 16u : 0u) +
            (size_t)block * bvh_stack_levels(sc) * 2u + 16u;
 }
 
@@ -247,11 +247,23 @@ struct BvhLds {
     unsigned short* stack; // this lane's column: stack[level * BLOCK]
 };
 
-template <int BLOCK>
+// LDS_NODES = false: the tree and the primitive geometry stay in HBM (scenes whose tree does not fit the
+// 160 KB of LDS, e.g. final_scene's 3.4 k primitives); only the traversal stacks live in LDS.
+template <int BLOCK, bool LDS_NODES>
 __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
     const uint32_t n_nodes = sc.n_bvh4_nodes, n_sph = sc.n_spheres;
     float4* base = reinterpret_cast<float4*>(smem);
     BvhLds L;
+    if (!LDS_NODES) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) L.pl[a] = sc.bvh4_p[a];
+        L.id = sc.bvh4_id;
+        L.geo = sc.prim_geo;
+        L.n_spheres = n_sph;
+        L.sc = &sc;
+        L.stack = reinterpret_cast<unsigned short*>(smem) + threadIdx.x;
+        return L;
+    }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         float4* dst = base + (size_t)a * n_nodes;
@@ -366,7 +378,7 @@ struct IntersectParams {
 // shading code the kernel needs ~40 VGPRs: two 1024-thread workgroups (8 waves per SIMD) share a
 // CU and hide each other's dependent LDS node fetches.
 // GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
-template <int BLOCK, bool GEN, bool RECTS>
+template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES>
 __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* __restrict__ qa,
                                                      const float4* __restrict__ qb, const float4* __restrict__ qc,
                                                      float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
@@ -385,8 +397,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
     }
     const uint32_t total = pre[RT_ISECT_MAX_SHARDS];
     if (total == 0) return; // block-uniform
-    const BvhLds L = stage_bvh<BLOCK>(sc, smem);
-    uint32_t* s_work = reinterpret_cast<uint32_t*>(smem + bvh_lds_bytes(sc, BLOCK) - 16u);
+    const BvhLds L = stage_bvh<BLOCK, LDS_NODES>(sc, smem);
+    uint32_t* s_work = reinterpret_cast<uint32_t*>(smem + bvh_lds_bytes(sc, BLOCK, LDS_NODES) - 16u);
     if (threadIdx.x == 0) *s_work = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -726,7 +738,7 @@ __global__ __launch_bounds__(256) void k_accum_counts(const uint32_t* __restrict
 }
 
 // Test hook: one bounce for caller-given rays, no queues (rt_debug_bounce).
-template <int BLOCK, bool USE_BVH>
+template <int BLOCK, bool USE_BVH, bool LDS_NODES>
 __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n, int depth, const float* __restrict__ in_o,
                                                         const float* __restrict__ in_d, const uint32_t* __restrict__ in_key,
                                                         int* __restrict__ out_hit, float* __restrict__ out_t,
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
     int hit = -1;
     const float a = length_squared(d);
     if (USE_BVH) {
-        const BvhLds L = stage_bvh<BLOCK>(sc, smem);
+        const BvhLds L = stage_bvh<BLOCK, LDS_NODES>(sc, smem);
         __syncthreads();
         if (active && sc.n_prims) {
             const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;

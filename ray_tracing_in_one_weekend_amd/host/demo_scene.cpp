@@ -2,7 +2,8 @@
 // path (demo_scene.rs:37-86 sphere_scene, demo_scene.rs:229-244 test_sphere) plus the two
 // build-authored scenes BASELINE.json configs 4 and 5 call for.  The other three reference
 // scenes: simple_light_scene (spheres + an XYRect) and cornell_box (rectangles, RotateY/Translate boxes that bound
-// two ConstantMedium) are mirrored below; final_scene (1000-sphere and 400-box sub-BVHs) is not yet.
+// two ConstantMedium) and final_scene (1000-sphere and 400-box sub-BVHs, an instanced sphere cloud, a
+// sphere-bounded medium) are mirrored below, so all five scenes of demo_scene.rs build here.
 #include "rtow.hpp"
 
 #include <cstdio>
@@ -150,6 +151,70 @@ std::pair<HitableList, Camera> cornell_box(float aspect_ratio) {
     };
     Camera cam = Camera::new_(vec3a(278.0f, 278.0f, -800.0f), vec3a(278.0f, 278.0f, 0.0f), vec3a(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio);
     return build_bvh(world, cam); // :147
+}
+
+// demo_scene.rs:150-221 — "the next week" final scene.  Thread-RNG consumption order is the reference's:
+// PerlinTex::new (:164), 1000 sphere centres (:176-178), the sphere BvhNode axes (:179), 400 box heights
+// (:184-198), the box BvhNode axes (:200), the world BvhNode axes (:220).
+std::pair<HitableList, Camera> final_scene(float aspect_ratio) {
+    SKY_COLOR_set(SkyFn::black_sky); // :151
+    auto ground = std::make_shared<Diffuse>(std::make_shared<ConstantTex>(vec3a(0.48f, 0.83f, 0.53f)));
+    auto white = std::make_shared<Diffuse>(std::make_shared<ConstantTex>(vec3a(0.73f, 0.73f, 0.73f)));
+    auto brown = std::make_shared<BurleyDiffuse>(std::make_shared<ConstantTex>(vec3a(0.7f, 0.3f, 0.1f)), 0.9f);
+    auto light = std::make_shared<Emission>(std::make_shared<ConstantTex>(vec3a(7.0f, 7.0f, 7.0f)));
+    auto dielectric = std::make_shared<Dielectric>(1.5f);
+    auto metal = std::make_shared<Metal>(vec3a(0.8f, 0.8f, 0.9f), 1.0f);
+
+    auto earth_map = ImageTex::new_("res/earthmap.jpg");
+    auto earth = std::make_shared<Sphere>(vec3a(400.0f, 200.0f, 400.0f), 100.0f, std::make_shared<Diffuse>(earth_map), "EarthSphere");
+    auto perlin = PerlinTex::new_(0.1f);
+    auto perlin_sphere = std::make_shared<Sphere>(vec3a(220.0f, 280.0f, 300.0f), 80.0f, std::make_shared<Diffuse>(perlin), "PerlinSphere");
+    auto brown_sphere = std::make_shared<Sphere>(vec3a(400.0f, 400.0f, 200.0f), 50.0f, brown, "BrownSphere");
+    auto dielectric_sphere = std::make_shared<Sphere>(vec3a(260.0f, 150.0f, 45.0f), 50.0f, dielectric, "DielectricSphere");
+    auto metal_sphere = std::make_shared<Sphere>(vec3a(0.0f, 150.0f, 145.0f), 50.0f, metal, "MetalSphere");
+    auto boundary = std::make_shared<Sphere>(vec3a(360.0f, 150.0f, 145.0f), 50.0f, dielectric, "boundary");
+    auto medium = ConstantMedium::new_(boundary, 0.2f, std::make_shared<ConstantTex>(vec3a(0.2f, 0.4f, 0.9f)));
+
+    HitableList spheres;
+    for (int i = 0; i < 1000; ++i) { // vec3a_random_range(0., 165.), math.rs:26-28
+        SmallRng& rng = RNG();
+        float x = rng.gen_f32(), y = rng.gen_f32(), z = rng.gen_f32();
+        spheres.push_back(std::make_shared<Sphere>(vec3a(x, y, z) * (165.0f - 0.0f) + 0.0f, 10.0f, white, "Ground"));
+    }
+    HitablePtr cloud = BvhNode::new_(spheres, 0, 1000);
+    cloud = RotateY::new_(cloud, 15.0f);
+    cloud = std::make_shared<Translate>(vec3a(-100.0f, 270.0f, 395.0f), cloud);
+
+    HitableList boxes;
+    for (int i = 0; i < 20; ++i) {
+        for (int j = 0; j < 20; ++j) {
+            const float w = 100.0f;
+            float x0 = -1000.0f + (float)i * w;
+            float z0 = -1000.0f + (float)j * w;
+            float y0 = 0.0f;
+            float x1 = x0 + w;
+            float y1 = RNG().gen_f32() * 100.0f + 1.0f;
+            float z1 = z0 + w;
+            boxes.push_back(GBox::new_(vec3a(x0, y0, z0), vec3a(x1, y1, z1), ground));
+        }
+    }
+    HitablePtr box_field = BvhNode::new_(boxes, 0, 20 * 20);
+
+    HitableList world = {
+        // min.y = 544 is the plane (hitable.rs:284-322 reads min[1]); max.y = 554 is ignored by hit()
+        std::make_shared<XZRect>(vec3a(123.0f, 544.0f, 147.0f), vec3a(423.0f, 554.0f, 412.0f), light),
+        cloud,
+        earth,
+        perlin_sphere,
+        brown_sphere,
+        dielectric_sphere,
+        metal_sphere,
+        box_field,
+        boundary,
+        medium,
+    };
+    Camera cam = Camera::new_(vec3a(478.0f, 278.0f, -600.0f), vec3a(278.0f, 278.0f, 0.0f), vec3a(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio);
+    return build_bvh(world, cam); // :220
 }
 
 // BASELINE.json config 4: earthmap-textured sphere under the newport_loft environment sky.

@@ -84,6 +84,7 @@ int rth_scene_build(const char* name, float aspect_ratio, RthScene** out) {
         else if (n == "test_sphere") fn = test_sphere;
         else if (n == "simple_light_scene") fn = simple_light_scene;
         else if (n == "cornell_box") fn = cornell_box;
+        else if (n == "final_scene") fn = final_scene;
         else if (n == "earth_env_scene") fn = earth_env_scene;
         else if (n == "pbr_sweep_scene") fn = pbr_sweep_scene;
         else throw std::runtime_error("rth_scene_build: unknown scene '" + n + "'");

@@ -678,6 +678,7 @@ std::pair<HitableList, Camera> sphere_scene(float aspect_ratio); // demo_scene.r
 std::pair<HitableList, Camera> test_sphere(float aspect_ratio);  // demo_scene.rs:229-244
 std::pair<HitableList, Camera> simple_light_scene(float aspect_ratio); // demo_scene.rs:88-110 (spheres + XYRect light)
 std::pair<HitableList, Camera> cornell_box(float aspect_ratio);        // demo_scene.rs:112-148 (walls + two smoke boxes)
+std::pair<HitableList, Camera> final_scene(float aspect_ratio);        // demo_scene.rs:150-221
 // Build-authored scenes from reference constructors (BASELINE.json configs 4 and 5; the
 // reference ships no scene for them).
 std::pair<HitableList, Camera> earth_env_scene(float aspect_ratio);

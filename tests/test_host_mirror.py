@@ -94,7 +94,7 @@ def test_piecewise_construction_and_errors(rt):
     s.finish()
     assert s.flat.n_spheres == 2 and s.flat.n_materials == 1 and s.flat.n_textures == 1
     with pytest.raises(rt.RtError):
-        rt.Scene.build("final_scene", 1.0)  # not mirrored yet (1000-sphere and 400-box sub-BVHs)
+        rt.Scene.build("no_such_scene", 1.0)
     s2 = rt.Scene.new()
     with pytest.raises(rt.RtError):
         s2.material(rt._ffi.MAT_DIFFUSE)  # Diffuse needs an albedo texture
@@ -134,3 +134,35 @@ def test_cornell_box_mirror(rt):
     # phase textures: black smoke, white smoke (demo_scene.rs:123,128)
     t0, t1 = a["mat_tex0"][a["med_mat"][0]], a["mat_tex0"][a["med_mat"][1]]
     assert a["tex_color0"][3 * t0:3 * t0 + 3].tolist() == [0, 0, 0] and a["tex_color0"][3 * t1:3 * t1 + 3].tolist() == [1, 1, 1]
+
+
+def test_final_scene_mirror(rt, orc):
+    """demo_scene.rs:150-221: 1000-sphere instanced cloud + 5 spheres + the world copy of `boundary` + its medium copy,
+    400 boxes + the light, RotateY(15) under Translate, one ConstantMedium(0.2) with a sphere boundary."""
+    s = rt.Scene.build("final_scene", 1.0)
+    a = s.arrays()
+    fs = s.flat
+    assert (fs.n_spheres, fs.n_rects, fs.n_xforms, fs.n_media, fs.n_materials) == (1007, 2401, 2, 1, 9)
+    assert fs.sky_type == rt._ffi.SKY_BLACK
+    # flatten order follows the world vector: light rect first, cloud spheres first among the spheres
+    rmin = a["rect_min"].reshape(-1, 3)
+    assert a["rect_axis"][0] == rt._ffi.RECT_XZ and rmin[0].tolist() == [123.0, 544.0, 147.0]
+    cloud = np.stack([a["sph_cx"][:1000], a["sph_cy"][:1000], a["sph_cz"][:1000]], axis=1)
+    assert (cloud >= 0).all() and (cloud < 165).all() and (a["sph_r"][:1000] == 10).all()
+    assert (a["sph_xform"][:1000] == a["sph_xform"][0]).all() and a["sph_xform"][0] != rt._ffi.NO_XFORM
+    assert (a["sph_xform"][1000:] == rt._ffi.NO_XFORM).all() and (a["rect_xform"] == rt._ffi.NO_XFORM).all()
+    chain = a["sph_xform"][0]      # innermost wrapper first: RotateY, whose parent is the Translate
+    assert a["xf_type"][chain] == rt._ffi.XF_ROTATE_Y and a["xf_type"][a["xf_parent"][chain]] == rt._ffi.XF_TRANSLATE
+    assert a["xf_param"].reshape(-1, 4)[a["xf_parent"][chain]][:3].tolist() == [-100.0, 270.0, 395.0]
+    # `boundary` appears twice: as a glass sphere of the world and as the medium's boundary
+    assert a["sph_medium"].tolist() == [rt._ffi.NO_XFORM] * 1006 + [0]
+    assert [a[k][1005] for k in ("sph_cx", "sph_cy", "sph_cz", "sph_r")] == [a[k][1006] for k in ("sph_cx", "sph_cy", "sph_cz", "sph_r")]
+    assert a["med_neg_inv_density"].tolist() == [-5.0]
+    # thread-RNG order: Perlin tables first (768 floats + 3 shuffles), then the cloud, then the box heights
+    want_c = np.zeros(3000, np.float32)
+    want_h = np.zeros(400, np.float32)
+    orc.load().orc_final_scene_layout(1995, orc._fp(want_c), orc._fp(want_h))
+    assert np.array_equal(cloud.view(np.uint32), want_c.reshape(1000, 3).view(np.uint32))
+    heights = rmin[1:][3::6, 1]   # side 3 of every GBox is the top XZRect, whose plane is y = max.y (hitable.rs:372-379)
+    assert heights.shape == (400,) and np.array_equal(heights.view(np.uint32), want_h.view(np.uint32))
+    assert (heights >= 1).all() and (heights < 101).all()
