@@ -141,7 +141,9 @@ typedef struct RtFlatScene {
      * n_spheres + n_rects + i and its hit() does the two boundary queries and the one random draw of
      * hitable.rs:540-568.  Its material is the Isotropic phase function (material.rs:99-113). */
     uint32_t n_media;
-    const float* med_neg_inv_density; /* [n_media] -1/density */
+    const float* med_neg_inv_density; /* [n_media] -1/(k*density), k = how many times the scene's own tree calls the
+                                       * medium per visit: 2 for each enclosing BvhNode that holds it as its only
+                                       * object (left == right, hitable.rs:188, 236-237), else 1 */
     const uint32_t* med_mat;          /* [n_media] material index (RT_MAT_ISOTROPIC) */
     const uint32_t* sph_medium;       /* [n_spheres] owning medium or RT_NO_MEDIUM; NULL = none */
     const uint32_t* rect_medium;      /* [n_rects] likewise */

@@ -714,6 +714,12 @@ bool bvh_hit(const RtFlatScene& fs, const Bvh& bvh, int node, const Ray& r, floa
     if (node < 0) return entry_hit(fs, ~node, r, t_min, t_max, rec, rng);
     const BvhNode& n = bvh.nodes[(size_t)node];
     if (!aabb_hit(n.box, r, t_min, t_max)) return false;
+    /* A node over one object holds it as both children (hitable.rs:188) and calls it twice.  That is idempotent
+     * for a surface; a ConstantMedium draws a second free path and the nearer wins, i.e. its density doubles.
+     * Which media sit alone in a node is a property of the scene's own (nested) tree, so the flattening folds
+     * that multiplicity into med_neg_inv_density (host/rtow.hpp ConstantMedium::flatten) and this tree over the
+     * flat entries must not add one of its own: */
+    if (n.left == n.right) return bvh_hit(fs, bvh, n.left, r, t_min, t_max, rec, rng);
     bool hit_left = bvh_hit(fs, bvh, n.left, r, t_min, t_max, rec, rng);
     bool hit_right = bvh_hit(fs, bvh, n.right, r, t_min, hit_left ? rec.t : t_max, rec, rng);
     return hit_left || hit_right;

@@ -25,6 +25,7 @@
 #pragma once
 #include "../../include/rtow_mi355x.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -33,6 +34,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <set>
 #include <utility>
 #include <vector>
 
@@ -232,6 +234,7 @@ class FlatSceneBuilder {
     std::vector<float> med_neg_inv_density;
     std::vector<uint32_t> med_mat, sph_medium, rect_medium;
     uint32_t cur_medium = RT_NO_MEDIUM;
+    uint32_t visit_mult = 1; // how many times BvhNode::hit calls the object being flattened per visit (see ConstantMedium)
     std::vector<uint8_t> mat_type;
     std::vector<float> mat_color, mat_p0, mat_p1, mat_p2, mat_p3;
     std::vector<uint32_t> mat_tex0, mat_tex1;
@@ -465,11 +468,20 @@ inline uint32_t FlatSceneBuilder::add_image(const ImageTex* t) {
 }
 
 // ---- hitable.rs --------------------------------------------------------------------------------------
+struct AABB { // math.rs:90-94 (#[derive(Default)]: zeros)
+    Vec3A min, max;
+    AABB surround(AABB rhs) const { // math.rs:115-130; f32::min/max
+        return AABB{vec3a(std::fmin(min.x, rhs.min.x), std::fmin(min.y, rhs.min.y), std::fmin(min.z, rhs.min.z)),
+                    vec3a(std::fmax(max.x, rhs.max.x), std::fmax(max.y, rhs.max.y), std::fmax(max.z, rhs.max.z))};
+    }
+};
+
 class Hitable {
   public:
     virtual ~Hitable() = default;
     virtual void flatten(FlatSceneBuilder& b) const = 0;
-    virtual std::string memo() const = 0; // hitable.rs:53
+    virtual bool bbox(AABB& aabb) const = 0; // hitable.rs:52 (BvhNode::new sorts by it)
+    virtual std::string memo() const = 0;    // hitable.rs:53
 };
 using HitablePtr = std::shared_ptr<const Hitable>;
 using HitableList = std::vector<HitablePtr>; // hitable.rs:114
@@ -481,6 +493,10 @@ struct Sphere : Hitable { // hitable.rs:57-62
     std::string name;
     Sphere(Vec3A c_, float r_, MaterialPtr m, std::string n) : c(c_), r(r_), mat(std::move(m)), name(std::move(n)) {}
     void flatten(FlatSceneBuilder& b) const override { b.push_sphere(c, r, b.intern_material(mat.get()), name); }
+    bool bbox(AABB& aabb) const override { // hitable.rs:104-108
+        aabb.min = c + (-r), aabb.max = c + r;
+        return true;
+    }
     std::string memo() const override { return name; }
 };
 
@@ -491,6 +507,13 @@ struct Sphere : Hitable { // hitable.rs:57-62
         MaterialPtr mat;                                                                                 \
         Name(Vec3A mn, Vec3A mx, MaterialPtr m) : min(mn), max(mx), mat(std::move(m)) {}                 \
         void flatten(FlatSceneBuilder& b) const override { b.push_rect(AXIS, min, max, b.intern_material(mat.get())); } \
+        bool bbox(AABB& aabb) const override { /* hitable.rs:274-278, 314-318, 354-358 */                 \
+            const int k = AXIS == RT_RECT_XY ? 2 : AXIS == RT_RECT_XZ ? 1 : 0;                             \
+            float mn[3] = {min.x, min.y, min.z}, mx[3] = {max.x, max.y, max.z};                           \
+            mn[k] = mn[k] - 0.0001f, mx[k] = mx[k] + 0.0001f;                                             \
+            aabb.min = vec3a(mn[0], mn[1], mn[2]), aabb.max = vec3a(mx[0], mx[1], mx[2]);                 \
+            return true;                                                                                 \
+        }                                                                                                \
         std::string memo() const override { return MEMO; }                                               \
     }
 RTOW_RECT(XYRect, RT_RECT_XY, "XYRect"); // hitable.rs:244-282
@@ -503,6 +526,7 @@ class GBox : public Hitable {
   public:
     static std::shared_ptr<GBox> new_(Vec3A min, Vec3A max, MaterialPtr mat) {
         auto g = std::shared_ptr<GBox>(new GBox());
+        g->aabb_ = AABB{min, max};
         g->sides_ = {
             std::make_shared<XYRect>(vec3a(min.x, min.y, min.z), vec3a(max.x, max.y, min.z), mat),
             std::make_shared<XYRect>(vec3a(min.x, min.y, max.z), vec3a(max.x, max.y, max.z), mat),
@@ -516,9 +540,14 @@ class GBox : public Hitable {
     void flatten(FlatSceneBuilder& b) const override {
         for (auto& s : sides_) s->flatten(b);
     }
+    bool bbox(AABB& aabb) const override { // hitable.rs:394-397
+        aabb = aabb_;
+        return true;
+    }
     std::string memo() const override { throw std::runtime_error("GBox::memo: todo!() in the reference (hitable.rs:399-401)"); }
 
   private:
+    AABB aabb_;
     HitableList sides_;
 };
 
@@ -531,6 +560,12 @@ struct Translate : Hitable {
         const uint32_t prev = b.push_xform(RT_XF_TRANSLATE, offset.x, offset.y, offset.z);
         ptr->flatten(b);
         b.pop_xform(prev);
+    }
+    bool bbox(AABB& aabb) const override { // hitable.rs:420-431
+        AABB got;
+        if (!ptr->bbox(got)) return false;
+        aabb = AABB{got.min + offset, got.max + offset};
+        return true;
     }
     std::string memo() const override { throw std::runtime_error("Translate::memo: todo!() in the reference (hitable.rs:433-435)"); }
 };
@@ -545,7 +580,24 @@ class RotateY : public Hitable {
         const float radians = angle * (3.14159265358979323846f / 180.0f);
         r->sin_theta_ = std::sin(radians);
         r->cos_theta_ = std::cos(radians);
+        AABB in; // hitable.rs:449-474: bounds of the 8 rotated corners
+        r->has_box_ = r->ptr_->bbox(in);
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    const float x = i == 0 ? in.min.x : in.max.x;
+                    const float y = j == 0 ? in.min.y : in.max.y;
+                    const float z = k == 0 ? in.min.z : in.max.z;
+                    const float tester[3] = {r->cos_theta_ * x + r->sin_theta_ * z, y, -r->sin_theta_ * x + r->cos_theta_ * z};
+                    for (int c = 0; c < 3; ++c) mn[c] = std::fmin(mn[c], tester[c]), mx[c] = std::fmax(mx[c], tester[c]);
+                }
+        r->aabb_ = AABB{vec3a(mn[0], mn[1], mn[2]), vec3a(mx[0], mx[1], mx[2])};
         return r;
+    }
+    bool bbox(AABB& aabb) const override { // hitable.rs:511-514
+        aabb = aabb_;
+        return has_box_;
     }
     void flatten(FlatSceneBuilder& b) const override {
         const uint32_t prev = b.push_xform(RT_XF_ROTATE_Y, sin_theta_, cos_theta_, angle_);
@@ -557,6 +609,8 @@ class RotateY : public Hitable {
   private:
     HitablePtr ptr_;
     float angle_ = 0, sin_theta_ = 0, cos_theta_ = 1;
+    bool has_box_ = false;
+    AABB aabb_;
 };
 
 // hitable.rs:523-588 — ConstantMedium::new(boundary, density, phase_fn_texture); the phase function is
@@ -570,11 +624,15 @@ class ConstantMedium : public Hitable {
         m->neg_inv_density_ = -1.0f / density;
         return m;
     }
+    // A BvhNode over a single object holds it as both children and hit() calls both (hitable.rs:188, 236-237).
+    // That is idempotent for a surface, but a medium draws a fresh free path on each call and the nearer of the
+    // two wins: the medium behaves as one of b.visit_mult times the density.  The flat scene carries that rate.
     void flatten(FlatSceneBuilder& b) const override {
-        b.begin_medium(neg_inv_density_, b.intern_material(phase_fn_.get()));
+        b.begin_medium(neg_inv_density_ / (float)b.visit_mult, b.intern_material(phase_fn_.get()));
         boundary_->flatten(b);
         b.end_medium();
     }
+    bool bbox(AABB& aabb) const override { return boundary_->bbox(aabb); } // hitable.rs:581-583
     std::string memo() const override { throw std::runtime_error("ConstantMedium::memo: todo!() in the reference (hitable.rs:585-587)"); }
 
   private:
@@ -583,32 +641,73 @@ class ConstantMedium : public Hitable {
     float neg_inv_density_ = 0;
 };
 
-// hitable.rs:158-221.  The accelerated path does its own closest-hit search, so the mirror
-// keeps the primitives of [start, end) in construction order and replays only the RNG side
-// effect of the reference constructor (one gen_range(0..3) per node, hitable.rs:182-184).
+// hitable.rs:158-221.  The accelerated path does its own closest-hit search, so flatten() emits the primitives
+// of [start, end) in construction order; the constructor still does everything the reference's does — one
+// gen_range(0..3) per node, the stable sort of objects[start..end) by box_compare, the surrounding box — because
+// the shape of the tree decides which objects sit alone in a node and are therefore hit twice per visit.
 class BvhNode : public Hitable {
   public:
     static std::shared_ptr<BvhNode> new_(HitableList& objects, size_t start, size_t end) {
         if (end <= start || end > objects.size()) throw std::runtime_error("BvhNode::new: empty span (unimplemented!() in the reference)");
-        draw_axes(end - start);
         auto n = std::shared_ptr<BvhNode>(new BvhNode());
         n->items_.assign(objects.begin() + (long)start, objects.begin() + (long)end);
+        n->aabb_ = n->build(objects, start, end);
         return n;
     }
     void flatten(FlatSceneBuilder& b) const override {
-        for (auto& h : items_) h->flatten(b);
-    }
-    std::string memo() const override { return "BvhNode"; }
-
-  private:
-    static void draw_axes(size_t span) {
-        (void)RNG().gen_range_usize(3);
-        if (span > 2) {
-            draw_axes(span / 2);
-            draw_axes(span - span / 2);
+        for (auto& h : items_) {
+            const uint32_t saved = b.visit_mult;
+            if (twice_.count(h.get())) b.visit_mult *= 2u;
+            h->flatten(b);
+            b.visit_mult = saved;
         }
     }
+    bool bbox(AABB& aabb) const override { // hitable.rs:228-231
+        aabb = aabb_;
+        return true;
+    }
+    std::string memo() const override { return "BvhNode"; }
+    // objects that ended up alone in a node (left == right, hitable.rs:188)
+    size_t n_visited_twice() const { return twice_.size(); }
+
+  private:
+    static int32_t total_key(float f) { // f32::total_cmp
+        int32_t b;
+        std::memcpy(&b, &f, 4);
+        b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+        return b;
+    }
+    static float axis_min(const HitablePtr& h, size_t axis) { // box_compare, hitable.rs:163-174
+        AABB box;
+        (void)h->bbox(box); // "No bounding box in bvh_node constructor." is only a message in the reference
+        return axis == 0 ? box.min.x : axis == 1 ? box.min.y : box.min.z;
+    }
+    AABB build(HitableList& objects, size_t start, size_t end) { // hitable.rs:177-221
+        const size_t axis = (size_t)RNG().gen_range_usize(3);
+        const size_t span = end - start;
+        AABB box_a, box_b;
+        if (span == 1) {
+            twice_.insert(objects[start].get());
+            (void)objects[start]->bbox(box_a);
+            box_b = box_a;
+        } else {
+            std::stable_sort(objects.begin() + (long)start, objects.begin() + (long)end, [&](const HitablePtr& a, const HitablePtr& b) {
+                return total_key(axis_min(a, axis)) < total_key(axis_min(b, axis));
+            });
+            if (span == 2) {
+                (void)objects[start]->bbox(box_a);
+                (void)objects[start + 1]->bbox(box_b);
+            } else {
+                const size_t mid = start + span / 2;
+                box_a = build(objects, start, mid);
+                box_b = build(objects, mid, end);
+            }
+        }
+        return box_a.surround(box_b);
+    }
     HitableList items_;
+    std::set<const Hitable*> twice_;
+    AABB aabb_;
 };
 
 // ---- lib.rs:11 SKY_COLOR, demo_scene.rs:19 ENV_TEX ------------------------------------------------------

@@ -166,3 +166,28 @@ def test_final_scene_mirror(rt, orc):
     heights = rmin[1:][3::6, 1]   # side 3 of every GBox is the top XZRect, whose plane is y = max.y (hitable.rs:372-379)
     assert heights.shape == (400,) and np.array_equal(heights.view(np.uint32), want_h.view(np.uint32))
     assert (heights >= 1).all() and (heights < 101).all()
+
+
+def test_bvh_shape_decides_medium_visit_count(rt):
+    """hitable.rs:177-221: a span of 3 splits 1 + 2 after the sort by box min, so the object with the smallest
+    coordinates sits alone in a node (left == right) and BvhNode::hit calls it twice; for a ConstantMedium that
+    doubles the scatter rate.  Positions are ordered the same on every axis, so the axis draw does not matter;
+    construction order is shuffled to show that the sort, not the order, decides."""
+    s = rt.Scene.new()
+    glass = s.material(rt._ffi.MAT_DIELECTRIC, p=(1.5, 0, 0, 0))
+    tex = s.constant_tex((1, 1, 1))
+    for c in ((0, 0, 0), (3, 3, 3), (-3, -3, -3)):
+        s.constant_medium(s.sphere(c, 1.0, glass, "b"), 0.5, tex)
+    s.set_camera((0, 0, 20), (0, 0, 0), (0, 1, 0), 40, 1.0)
+    s.finish(use_bvh=True)
+    a = s.arrays()
+    assert a["sph_cx"].tolist() == [0.0, 3.0, -3.0]                     # flatten keeps construction order
+    assert a["med_neg_inv_density"].tolist() == [-2.0, -2.0, -1.0]      # only the ball at (-3,-3,-3) is alone
+    s = rt.Scene.new()
+    glass = s.material(rt._ffi.MAT_DIELECTRIC, p=(1.5, 0, 0, 0))
+    tex = s.constant_tex((1, 1, 1))
+    for c in ((0, 0, 0), (3, 3, 3), (-3, -3, -3)):
+        s.constant_medium(s.sphere(c, 1.0, glass, "b"), 0.5, tex)
+    s.set_camera((0, 0, 20), (0, 0, 0), (0, 1, 0), 40, 1.0)
+    s.finish(use_bvh=False)                                              # a plain HitableList visits each object once
+    assert s.arrays()["med_neg_inv_density"].tolist() == [-2.0, -2.0, -2.0]

@@ -159,3 +159,34 @@ def test_cornell_box_oracle(rt, orc):
     assert abs(int(sa.n_rays) - int(sb.n_rays)) / sa.n_rays < 1e-3 and (np.abs(a - b).max(axis=2) > 1e-4).mean() < 5e-3
     assert abs(a.mean() - c.mean()) / a.mean() < 0.03 and np.isfinite(a).all()
     assert a.max() <= 7.0 + 1e-4  # the light is (7,7,7)
+
+
+def _smoke_ball(rt, density, use_bvh=False):
+    """A ConstantMedium with a black phase function bounded by a unit sphere 10 away, seen through a 1-degree lens
+    under a constant-1 sky: radiance = P(no scatter along the chord) = exp(-density * chord) (hitable.rs:541-583)."""
+    rt.register_image("test/white.png", np.ones((4, 8, 3), np.float32))
+    s = rt.Scene.new()
+    glass = s.material(rt._ffi.MAT_DIELECTRIC, p=(1.5, 0, 0, 0))
+    ball = s.sphere((0, 0, -10), 1.0, glass, "boundary")   # the boundary's own material is never used by the medium
+    s.constant_medium(ball, density, s.constant_tex((0, 0, 0)))
+    s.set_sky(rt._ffi.SKY_ENV, "test/white.png")
+    s.set_camera((0, 0, 0), (0, 0, -10), (0, 1, 0), 1.0, 1.0)
+    s.finish(use_bvh=use_bvh)
+    return s
+
+
+def test_medium_transmittance_is_beer_lambert(rt, orc):
+    """Also pins a quirk of the reference: build_bvh over a one-object world makes BvhNode{left == right} and
+    BvhNode::hit calls both (hitable.rs:188, 236-237), so the medium draws two free paths per visit and behaves as
+    one of twice the density.  The host mirror reproduces the tree and flattens that rate."""
+    for density in (0.5, 1.5):
+        for use_bvh, rate in ((False, density), (True, 2 * density)):
+            s = _smoke_ball(rt, density, use_bvh)
+            assert s.flat.n_media == 1 and s.flat.n_spheres == 1
+            assert s.arrays()["med_neg_inv_density"][0] == np.float32(-1.0) / np.float32(rate)
+            p = rt.make_params(64, 64, 64, max_depth=50)
+            lo, hi = np.exp(-rate * 2.0), np.exp(-rate * 2.0 * np.sqrt(1 - 0.0873 ** 2))  # chord at centre / frame corner
+            for opts in (orc.options(accel=orc.ACCEL_LIST), orc.options(accel=orc.ACCEL_BVH), orc.options(rng_mode=orc.RNG_STREAM)):
+                img, _, _ = orc.render(s.flat_ptr, s.camera, p, opts)
+                assert img.max() <= 1.0   # every path is all or nothing
+                assert lo - 0.004 < img.mean() < hi + 0.004, (density, use_bvh, img.mean(), lo, hi)
