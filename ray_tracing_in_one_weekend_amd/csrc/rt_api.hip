@@ -394,6 +394,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     std::vector<uint32_t> pmed(n_prims, RT_NO_MEDIUM), med_prims;
     std::vector<uint2> med_range(s->n_media);
     std::vector<float> med_nid(s->n_media);
+    std::vector<uint32_t> med_xf(s->n_media, RT_NO_XFORM);
     for (uint32_t i = 0; i < n_prims; ++i)
         pmed[i] = i < s->n_spheres ? (s->sph_medium ? s->sph_medium[i] : RT_NO_MEDIUM)
                                    : (s->rect_medium ? s->rect_medium[i - s->n_spheres] : RT_NO_MEDIUM);
@@ -408,6 +409,9 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         for (int k = 0; k < 3; ++k) mb.mn[k] = FLT_MAX, mb.mx[k] = -FLT_MAX;
         for (uint32_t i = 0; i < n_prims; ++i)
             if (pmed[i] == m) {
+                // one wrapper chain for the whole boundary (a GBox under RotateY/Translate): medium_root moves the ray once
+                if (med_range[m].y == 0) med_xf[m] = pxf[i];
+                else if (med_xf[m] != pxf[i]) med_xf[m] = RT_MED_XF_MIXED;
                 med_prims.push_back(i);
                 ++med_range[m].y;
                 for (int k = 0; k < 3; ++k) mb.mn[k] = std::min(mb.mn[k], pboxes[i].mn[k]), mb.mx[k] = std::max(mb.mx[k], pboxes[i].mx[k]);
@@ -453,6 +457,15 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     ds.n_rects = s->n_rects;
     ds.n_prims = n_prims;
     ds.n_bvh4_nodes = (uint32_t)bvh4.id.size();
+    {   // rays whose slab slack exceeds 2^-10 of the scene extent use the cancellation-free slab test (bvh_step)
+        double ext2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            float lo = FLT_MAX, hi = -FLT_MAX;
+            for (const PrimBox& b : eboxes) lo = std::min(lo, b.mn[k]), hi = std::max(hi, b.mx[k]);
+            if (hi > lo) ext2 += ((double)hi - lo) * ((double)hi - lo);
+        }
+        ds.bvh_exact_eps = (float)(std::sqrt(ext2) / 1024.0);
+    }
     ds.bvh4_depth = bvh4.depth;
     ds.n_spheres = s->n_spheres, ds.n_materials = s->n_materials, ds.n_textures = s->n_textures;
     ds.n_perlin = s->n_perlin, ds.n_images = s->n_images, ds.sky_type = s->sky_type, ds.sky_image = s->sky_image;
@@ -462,7 +475,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     if ((rc = upload(ctx, pgeo, &ds.prim_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
         (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
-        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, pmed, &ds.prim_medium)) || (rc = upload(ctx, med_prims, &ds.med_prims)) || (rc = upload(ctx, med_range, &ds.med_range)) ||
+        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, pmed, &ds.prim_medium)) || (rc = upload(ctx, med_prims, &ds.med_prims)) || (rc = upload(ctx, med_range, &ds.med_range)) || (rc = upload(ctx, med_xf, &ds.med_xform)) ||
         (rc = upload(ctx, med_nid, &ds.med_neg_inv_density)) || (rc = upload(ctx, pxf, &ds.prim_xform)) || (rc = upload(ctx, xparam, &ds.xf_param)) ||
         (rc = upload(ctx, xmeta, &ds.xf_meta)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
         (rc = upload(ctx, bvh4.p[0], &ds.bvh4_p[0])) || (rc = upload(ctx, bvh4.p[1], &ds.bvh4_p[1])) ||

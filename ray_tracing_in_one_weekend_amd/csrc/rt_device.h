@@ -185,6 +185,8 @@ struct DevScene {
     const float* med_neg_inv_density;
     const uint2* med_range;
     const uint32_t* med_prims;
+    float bvh_exact_eps;       // slab slack above which a ray takes the cancellation-free test (2^-10 of the scene extent)
+    const uint32_t* med_xform; // [n_media] wrapper chain shared by all boundary primitives, or RT_MED_XF_MIXED
     const uint32_t* prim_medium; // [n_prims] owning medium or 0xFFFFFFFF
     uint32_t n_rects;   // axis-aligned rectangles; primitive index = n_spheres + rect index
     uint32_t n_prims;   // n_spheres + n_rects

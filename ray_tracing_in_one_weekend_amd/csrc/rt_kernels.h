@@ -145,14 +145,25 @@ __device__ __forceinline__ bool prim_root(const DevScene& sc, const float4* geo,
     const uint32_t gi = sc.n_spheres + 2u * (s - sc.n_spheres);
     return rect_root(geo[gi], geo[gi + 1u], o, d, t_min, t_max, th);
 }
+// Root of one boundary primitive for a ray that is already in the object space of the medium's common chain
+// (RAW) or still in world space (the primitive applies its own chain).
+template <bool RAW>
+__device__ __forceinline__ bool boundary_prim_root(const DevScene& sc, const float4* geo, uint32_t s, V3 o, V3 d,
+                                                   float t_min, float t_max, float& th) {
+    if (!RAW) return prim_root(sc, geo, s, o, d, t_min, t_max, th);
+    if (s < sc.n_spheres) return sphere_root(geo[s], o, d, length_squared(d), t_min, t_max, th);
+    const uint32_t gi = sc.n_spheres + 2u * (s - sc.n_spheres);
+    return rect_root(geo[gi], geo[gi + 1u], o, d, t_min, t_max, th);
+}
 // boundary.hit(r, t_min, t_max): closest accepted root over the medium's boundary primitives
+template <bool RAW>
 __device__ __forceinline__ bool boundary_root(const DevScene& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
                                               float t_max, float& t_out) {
     const uint2 rg = sc.med_range[m];
     bool any = false;
     for (uint32_t k = 0; k < rg.y; ++k) {
         float th;
-        if (prim_root(sc, geo, sc.med_prims[rg.x + k], o, d, t_min, t_max, th)) {
+        if (boundary_prim_root<RAW>(sc, geo, sc.med_prims[rg.x + k], o, d, t_min, t_max, th)) {
             t_max = th;
             any = true;
         }
@@ -160,20 +171,34 @@ __device__ __forceinline__ bool boundary_root(const DevScene& sc, const float4* 
     t_out = t_max;
     return any;
 }
+#define RT_MED_XF_MIXED 0xFFFFFFFEu // the boundary's primitives do not share one wrapper chain
 // ConstantMedium::hit, hitable.rs:536-579, up to the accepted t.  The random draw is counter slot
 // 224 + m of the depth block (DESIGN.md "RNG"): independent of the order in which media are visited.
 // t_max clamps like the reference's (hitable.rs:553-555); callers pass FLT_MAX and apply the
 // order-independent winner rule, which differs from the clamp only by rounding at exact ties.
+// `t_cull`: a scatter point cannot lie before the entry t1, so a medium entered beyond the best hit so far
+// cannot win and the second boundary search is skipped (pure culling, no effect on the result).
+// When all boundary primitives sit below the same wrapper chain (a GBox under RotateY/Translate) the ray is
+// moved to object space once instead of once per primitive and search — the same bits either way.
 __device__ __forceinline__ bool medium_root(const DevScene& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
-                                            float t_max, const MediumCtx& mc, float& t_hit) {
+                                            float t_max, float t_cull, const MediumCtx& mc, float& t_hit) {
     float t1, t2;
-    if (!boundary_root(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
-    if (!boundary_root(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
+    const float ray_len = length(d); // of the world-space ray, hitable.rs:560
+    const uint32_t cx = sc.med_xform[m];
+    if (cx != RT_MED_XF_MIXED) {
+        if (cx != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, cx), o, d);
+        if (!boundary_root<true>(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
+        if (t1 > t_cull) return false;
+        if (!boundary_root<true>(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
+    } else {
+        if (!boundary_root<false>(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
+        if (t1 > t_cull) return false;
+        if (!boundary_root<false>(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
+    }
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return false;
     if (t1 < 0.0f) t1 = 0.0f;
-    const float ray_len = length(d);
     const float dist_inside_boundary = (t2 - t1) * ray_len;
     const uint32_t r = fmix32(fmix32(mc.k0 ^ ((mc.base + 224u + m) * 0x9E3779B9u)) + mc.k1);
     const float xi = (float)(r >> 8) * (1.0f / 16777216.0f);
@@ -200,7 +225,7 @@ __device__ __forceinline__ void closest_hit_rects(const DevScene& sc, V3 o, V3 d
     }
     for (uint32_t m = 0; m < sc.n_media; ++m) {
         float th;
-        if (medium_root(sc, sc.prim_geo, m, o, d, 1e-3f, tbest, mc, th)) {
+        if (medium_root(sc, sc.prim_geo, m, o, d, 1e-3f, tbest, tbest, mc, th)) {
             tbest = th;
             hit = (int)(sc.n_prims + m);
         }
@@ -299,10 +324,13 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
 // The rounding of the precomputed o*inv puts an ABSOLUTE error of up to 2^-24*|o*inv| on every plane
 // distance — large when the ray is nearly perpendicular to an axis — so the per-ray slack
 // `eps` = 2.4e-7*max|o*inv| (2x the bound for entry + exit) is added to both limits, next to the 4e-6
-// relative widening that covers the rounding of inv and of the fma itself.
+// relative widening that covers the rounding of inv and of the fma itself.  For the few rays where that
+// slack grows to the size of the scene (a direction component below ~1e-4: o*inv cancels against b*inv
+// and nothing is culled any more — harmless for a tree in LDS, milliseconds for one wave walking 1 000
+// nodes out of HBM) `exact` selects (b - o)*inv, which has no cancellation, with eps = 0.
 template <int BLOCK, bool RECTS>
 __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float nox, float noy,
-                                         float noz, float eps, float a, const MediumCtx& mc, int& cur, int& sp,
+                                         float noz, float eps, bool exact, float a, uint32_t& pend, int& cur, int& sp,
                                          float& tbest, int& hit) {
     if (cur >= 0) {
         const float4 mnx = L.pl[0][cur], mny = L.pl[1][cur], mnz = L.pl[2][cur];
@@ -313,9 +341,9 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
         int best = (int)0x80000000;
 #define RT_CHILD(K, IDK)                                                                                      \
     {                                                                                                         \
-        const float x0 = __builtin_fmaf(mnx.K, ix, nox), x1 = __builtin_fmaf(mxx.K, ix, nox);                 \
-        const float y0 = __builtin_fmaf(mny.K, iy, noy), y1 = __builtin_fmaf(mxy.K, iy, noy);                 \
-        const float z0 = __builtin_fmaf(mnz.K, iz, noz), z1 = __builtin_fmaf(mxz.K, iz, noz);                 \
+        const float x0 = RT_T(mnx.K, ix, nox, o.x), x1 = RT_T(mxx.K, ix, nox, o.x);                           \
+        const float y0 = RT_T(mny.K, iy, noy, o.y), y1 = RT_T(mxy.K, iy, noy, o.y);                           \
+        const float z0 = RT_T(mnz.K, iz, noz, o.z), z1 = RT_T(mxz.K, iz, noz, o.z);                           \
         const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));              \
         const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));                           \
         if (tn <= fminf(__builtin_fmaf(tf, 1.000004f, eps), tb) && IDK != (int)0x80000000) {                  \
@@ -332,10 +360,21 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
             }                                                                                                 \
         }                                                                                                     \
     }
-        RT_CHILD(x, id.x)
-        RT_CHILD(y, id.y)
-        RT_CHILD(z, id.z)
-        RT_CHILD(w, id.w)
+        if (!exact) {
+#define RT_T(B, INV, NO, O) __builtin_fmaf(B, INV, NO)
+            RT_CHILD(x, id.x)
+            RT_CHILD(y, id.y)
+            RT_CHILD(z, id.z)
+            RT_CHILD(w, id.w)
+#undef RT_T
+        } else { // rays almost parallel to an axis plane (see k_intersect): plane distances without cancellation
+#define RT_T(B, INV, NO, O) (((B) - (O)) * (INV))
+            RT_CHILD(x, id.x)
+            RT_CHILD(y, id.y)
+            RT_CHILD(z, id.z)
+            RT_CHILD(w, id.w)
+#undef RT_T
+        }
 #undef RT_CHILD
         if (best != (int)0x80000000) {
             cur = best;
@@ -349,12 +388,17 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
         if (!RECTS) {
             ok = sphere_root(L.geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th);
         } else {
-            // general scene: a medium, or a primitive that may sit below Translate / RotateY wrappers (t is
-            // unchanged by them)
-            if ((uint32_t)s >= L.sc->n_prims)
-                ok = medium_root(*L.sc, L.geo, (uint32_t)s - L.sc->n_prims, o, d, 1e-3f, RT_FLT_MAX, mc, th);
-            else
+            // general scene: a primitive that may sit below Translate / RotateY wrappers (t is unchanged by
+            // them), or a medium.  A medium costs two searches over its boundary, ~12x a rectangle; tested
+            // here it would stall the lanes of the wave that are at cheap leaves on every step.  It is only
+            // noted in `pend` and tested after the traversal (media_step), when the lanes of the wave do so
+            // together.  The winner rule is order-independent, so the result is the same.
+            if ((uint32_t)s >= L.sc->n_prims) {
+                pend |= 1u << ((uint32_t)s - L.sc->n_prims);
+                ok = false;
+            } else {
                 ok = prim_root(*L.sc, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
+            }
         }
         if (ok && (th < tbest || (th == tbest && s > hit))) {
             tbest = th;
@@ -366,6 +410,19 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
     cur = (int)(short)L.stack[sp * BLOCK];
     return false;
 }
+// Tests the lowest pending medium of this lane against the best hit so far; returns true when none is left.
+__device__ __forceinline__ bool media_step(const BvhLds& L, V3 o, V3 d, const MediumCtx& mc, uint32_t& pend, float& tbest,
+                                           int& hit) {
+    const uint32_t m = (uint32_t)__ffs((int)pend) - 1u;
+    pend &= pend - 1u;
+    const int s = (int)(L.sc->n_prims + m);
+    float th;
+    if (medium_root(*L.sc, L.geo, m, o, d, 1e-3f, RT_FLT_MAX, tbest, mc, th) && (th < tbest || (th == tbest && s > hit))) {
+        tbest = th;
+        hit = s;
+    }
+    return pend == 0u;
+}
 struct IntersectParams {
     uint32_t nq, cap;
     int depth;
@@ -375,11 +432,13 @@ struct IntersectParams {
 // Persistent lanes: a lane whose traversal has finished writes its hit record and, once enough
 // lanes of the wave are idle, the wave claims that many fresh rays from the workgroup's LDS work
 // counter (the shards of the workgroup are concatenated into one virtual index space).  With no
-// shading code the kernel needs ~40 VGPRs: two 1024-thread workgroups (8 waves per SIMD) share a
-// CU and hide each other's dependent LDS node fetches.
+// shading code the sphere-only kernel needs 58 VGPRs; the general one is held to 64 (second
+// __launch_bounds__ argument = waves per SIMD on AMD; 16 B of scratch in the cold path) so that two
+// 1024-thread workgroups (8 waves per SIMD) share a CU and hide each other's dependent node fetches
+// — measured +15 % on cornell_box and +20 % on final_scene against 7 waves = one workgroup.
 // GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
 template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES>
-__global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* __restrict__ qa,
+__global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float4* __restrict__ qa,
                                                      const float4* __restrict__ qb, const float4* __restrict__ qc,
                                                      float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
                                                      IntersectParams ip, const GenParams* __restrict__ gpd) {
@@ -405,6 +464,9 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
     const bool no_geometry = sc.n_prims == 0u;
     bool exhausted = false; // wave-uniform: the workgroup has no unclaimed rays left
     bool has = false;
+    bool exact = false; // this lane's ray uses the cancellation-free slab test (bvh_step)
+    bool trav = false;  // general scenes: has && !trav = traversal done, media of `pend` still to test
+    uint32_t pend = 0u;
     V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
     float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, eps = 0.f, a = 1.0f, tbest = RT_FLT_MAX;
     int hit = -1, cur = 0, sp = 0;
@@ -442,12 +504,16 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
                 ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
                 nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
                 eps = 2.4e-7f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
+                exact = !(eps <= sc.bvh_exact_eps); // also NaN (0 * inf)
+                if (exact) eps = 0.0f;
                 a = length_squared(d); // hitable.rs:77
                 tbest = RT_FLT_MAX;
                 hit = -1;
                 cur = 0;
                 sp = 0;
                 has = !no_geometry;
+                trav = true;
+                pend = 0u;
                 if (no_geometry) qh[pos] = make_float2(RT_FLT_MAX, __int_as_float(-1));
             }
         }
@@ -455,9 +521,24 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(DevScene sc, const float4* 
             if (exhausted) break;
             continue;
         }
-        if (has && bvh_step<BLOCK, RECTS>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, mc, cur, sp, tbest, hit)) {
-            qh[pos] = make_float2(tbest, __int_as_float(hit));
-            has = false;
+        if (RECTS) {
+            // media phase: when no lane of the wave has tree work left, or half the wave is waiting
+            const unsigned long long waiting = __ballot(has && !trav);
+            if (waiting && (__popcll(waiting) >= 32 || !__any(has && trav))) {
+                if (has && !trav && media_step(L, o, d, mc, pend, tbest, hit)) {
+                    qh[pos] = make_float2(tbest, __int_as_float(hit));
+                    has = false;
+                }
+                continue;
+            }
+        }
+        if (has && trav && bvh_step<BLOCK, RECTS>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit)) {
+            if (RECTS && pend) {
+                trav = false;
+            } else {
+                qh[pos] = make_float2(tbest, __int_as_float(hit));
+                has = false;
+            }
         }
     }
 }
@@ -762,10 +843,15 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
         if (active && sc.n_prims) {
             const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
             const float nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
-            const float eps = 2.4e-7f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
+            float eps = 2.4e-7f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
+            const bool exact = !(eps <= sc.bvh_exact_eps);
+            if (exact) eps = 0.0f;
             int cur = 0, sp = 0;
             const MediumCtx mc{active ? in_key[2 * i] : 0u, active ? in_key[2 * i + 1] : 0u, depth_counter_base(depth)};
-            while (!bvh_step<BLOCK, true>(L, o, d, ix, iy, iz, nox, noy, noz, eps, a, mc, cur, sp, tbest, hit)) {
+            uint32_t pend = 0u;
+            while (!bvh_step<BLOCK, true>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit)) {
+            }
+            while (pend && !media_step(L, o, d, mc, pend, tbest, hit)) {
             }
         }
     } else {
