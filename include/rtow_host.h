@@ -74,6 +74,17 @@ int rth_scene_camera(const RthScene* s, RtCamera* out);
 const char* rth_scene_sphere_name(const RthScene* s, uint32_t index);
 void rth_scene_free(RthScene* s);
 
+/* ---- driver conveniences (main.rs:109-128) -------------------------------------------------------------- */
+
+/* Saves rows*nx RGB8 pixels (row 0 = top, i.e. the layout rt_render's out_rgb8 already has after the flip of
+ * main.rs:127) as an 8-bit RGB PNG, what `img.save(file_name)` writes at main.rs:121,128.  The file appears
+ * atomically (written to <path>.part, then renamed), so it can be polled as a preview. */
+int rth_png_write(const char* path, const uint8_t* rgb8, uint32_t nx, uint32_t ny);
+
+/* The reference's output name (main.rs:110-112): local time as RFC 3339 with ':' replaced by '-', cut before the
+ * fractional seconds, + ".png", e.g. "2024-05-17T21-03-44.png".  unix_seconds < 0 = now.  buf_len >= 24. */
+int rth_output_file_name(int64_t unix_seconds, char* buf, uint32_t buf_len);
+
 #ifdef __cplusplus
 }
 #endif

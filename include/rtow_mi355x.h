@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4u
+#define RT_ABI_VERSION 5u
 
 /* error codes */
 #define RT_OK 0
@@ -283,6 +283,18 @@ int rt_render(RtCtx* ctx, const RtCamera* cam, const RtParams* params, float* ou
  */
 int rt_render_device(RtCtx* ctx, const RtCamera* cam, const RtParams* params,
                      void* d_out_rgb_f32, void* stream, RtStats* stats);
+
+/*
+ * Progressive preview.  Replaces the partial saves of the receive loop, main.rs:114-123 (there: every 10
+ * columns of pixels; here: after every slice of samples, the unit in which a wavefront renderer finishes
+ * work).  After each slice of a following rt_render() the callback gets the running mean of the samples
+ * done so far, quantised and flipped exactly like the final image (main.rs:98-105,127): rows_local*nx*3
+ * bytes, valid during the call.  The final image is unchanged by the callback; choose the preview cadence
+ * with RtParams.spp_slice.  NULL removes the callback.  rt_render_device() never calls it.
+ */
+typedef void (*RtProgressFn)(void* user, uint32_t spp_done, uint32_t spp_total, const uint8_t* rgb8, uint32_t nx,
+                             uint32_t rows);
+int rt_set_progress(RtCtx* ctx, RtProgressFn fn, void* user);
 
 /* Per-depth device times of the first slice of the last render that had RT_FLAG_TIME_DEPTHS set:
  * isect_ms[d] = closest-hit kernel, shade_ms[d] = shading kernel, rays[d] = rays traced at depth d

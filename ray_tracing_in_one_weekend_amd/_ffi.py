@@ -92,13 +92,16 @@ class RtBounceIO(C.Structure):
                 ("out_o", _f), ("out_d", _f), ("out_alive", _u8), ("flags", C.c_uint32)]
 
 
+# void (*RtProgressFn)(void* user, uint32_t spp_done, uint32_t spp_total, const uint8_t* rgb8, uint32_t nx, uint32_t rows)
+RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32)
+
 GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
                "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce",
-               "rt_get_depth_timings"]
+               "rt_get_depth_timings", "rt_set_progress"]
 HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
                 "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
                 "rth_sphere", "rth_rect", "rth_gbox", "rth_translate", "rth_rotate_y", "rth_constant_medium", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
-                "rth_scene_camera", "rth_scene_sphere_name", "rth_scene_free"]
+                "rth_scene_camera", "rth_scene_sphere_name", "rth_scene_free", "rth_png_write", "rth_output_file_name"]
 
 _gpu_lib = None
 _host_lib = None
@@ -140,6 +143,8 @@ def load_gpu_library():
     lib.rt_get_depth_timings.restype = C.c_int
     lib.rt_debug_bounce.argtypes = [vp, C.POINTER(RtBounceIO)]
     lib.rt_debug_bounce.restype = C.c_int
+    lib.rt_set_progress.argtypes = [vp, RtProgressFn, vp]
+    lib.rt_set_progress.restype = C.c_int
     _gpu_lib = lib
     return lib
 
@@ -198,6 +203,10 @@ def load_host_library():
     lib.rth_scene_sphere_name.argtypes = [vp, C.c_uint32]
     lib.rth_scene_sphere_name.restype = C.c_char_p
     lib.rth_scene_free.argtypes = [vp]
+    lib.rth_png_write.argtypes = [C.c_char_p, _u8, C.c_uint32, C.c_uint32]
+    lib.rth_png_write.restype = C.c_int
+    lib.rth_output_file_name.argtypes = [C.c_int64, C.c_char_p, C.c_uint32]
+    lib.rth_output_file_name.restype = C.c_int
     lib.rth_scene_free.restype = None
     _host_lib = lib
     return lib

@@ -215,6 +215,20 @@ class Renderer:
             self._raise("rt_render", rc)
         return img, rgb8, stats
 
+    def set_progress(self, fn):
+        """fn(spp_done, spp_total, rgb8[rows, nx, 3]) after every slice but the last of a following render()
+        (main.rs:114-123, the partial saves); None removes it.  Pick the cadence with make_params(spp_slice=...)."""
+        if fn is None:
+            self._progress = None
+            rc = self._lib.rt_set_progress(self._ctx, _ffi.RtProgressFn(), None)
+        else:
+            def tramp(_user, done, total, ptr, nx, rows):
+                fn(done, total, np.ctypeslib.as_array(ptr, shape=(rows, nx, 3)).copy())
+            self._progress = _ffi.RtProgressFn(tramp)  # keep the thunk alive as long as it is registered
+            rc = self._lib.rt_set_progress(self._ctx, self._progress, None)
+        if rc != 0:
+            self._raise("rt_set_progress", rc)
+
     def render_device(self, camera, params, device_ptr, stream=None, want_stats=True):
         """Renders into HBM at `device_ptr` (e.g. torch_tensor.data_ptr()); nothing crosses PCIe."""
         stats = RtStats()
@@ -268,3 +282,24 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+def save_png(path, rgb8):
+    """img.save(file_name) of main.rs:121,128: rgb8 is [ny, nx, 3] uint8 with row 0 at the top, as render(..., want_rgb8=True)
+    returns it.  Written by the host library (rth_png_write), atomically."""
+    lib = _ffi.load_host_library()
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("save_png: expected [ny, nx, 3] uint8")
+    rc = lib.rth_png_write(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[0])
+    if rc != 0:
+        raise RtError(f"rth_png_write({path}) failed ({rc})")
+
+
+def output_file_name(unix_seconds=-1):
+    """main.rs:110-112: local RFC 3339 time with ':' -> '-', cut before the fraction, + '.png'."""
+    lib = _ffi.load_host_library()
+    buf = C.create_string_buffer(64)
+    if lib.rth_output_file_name(int(unix_seconds), buf, 64) != 0:
+        raise RtError("rth_output_file_name failed")
+    return buf.value.decode()

@@ -29,7 +29,7 @@ def _run(cmd):
 def build_gpu_library(force=False):
     """hipcc --offload-arch=gfx950: HIP kernels + C-ABI -> librtow_mi355x.so"""
     csrc = os.path.join(PKG_DIR, "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("rt_api.hip", "rt_kernels.h", "rt_device.h")]
+    srcs = [os.path.join(csrc, f) for f in ("rt_api.hip", "rt_kernels.h", "rt_device.h", "rt_bvh.h")]
     srcs.append(os.path.join(ROOT, "include", "rtow_mi355x.h"))
     out = os.path.join(PKG_DIR, "librtow_mi355x.so")
     if force or _newer(out, srcs):
@@ -41,11 +41,11 @@ def build_gpu_library(force=False):
 def build_host_library(force=False):
     """g++: C++ mirror of the reference construction API + C handle API -> librtow_host.so"""
     host = os.path.join(PKG_DIR, "host")
-    srcs = [os.path.join(host, f) for f in ("demo_scene.cpp", "host_capi.cpp", "rtow.hpp")]
+    srcs = [os.path.join(host, f) for f in ("demo_scene.cpp", "host_capi.cpp", "png_out.cpp", "rtow.hpp")]
     srcs += [os.path.join(ROOT, "include", f) for f in ("rtow_mi355x.h", "rtow_host.h")]
     out = os.path.join(PKG_DIR, "librtow_host.so")
     if force or _newer(out, srcs):
-        _run(["g++"] + HOST_FLAGS + ["-o", out, srcs[0], srcs[1]])
+        _run(["g++"] + HOST_FLAGS + ["-o", out, srcs[0], srcs[1], srcs[2], "-lz"])
     return out
 
 

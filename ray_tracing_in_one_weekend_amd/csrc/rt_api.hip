@@ -50,6 +50,12 @@ struct RtCtx {
     bool use_bvh = false;      // scene BVH fits LDS next to the traversal stacks
     size_t isect_lds = 0;      // k_intersect: nodes + geometry (when they fit) + stack levels + counters
     bool bvh_in_lds = false;   // false: the tree is traversed out of HBM/L2, only the stacks are in LDS
+    // progressive preview (rt_set_progress): called from rt_render after every slice
+    RtProgressFn progress_fn = nullptr;
+    void* progress_user = nullptr;
+    bool progress_armed = false; // set by rt_render around render_impl, so rt_render_device stays callback-free
+    DevBuf preview_u8;
+    std::vector<uint8_t> preview_host;
 };
 
 namespace {
@@ -170,6 +176,7 @@ void rt_ctx_destroy(RtCtx* ctx) {
     for (auto& b : ctx->qbuf) free_buf(b);
     free_buf(ctx->rad), free_buf(ctx->acc), free_buf(ctx->counts), free_buf(ctx->totals);
     free_buf(ctx->out_f32), free_buf(ctx->out_u8), free_buf(ctx->dbg), free_buf(ctx->qhit), free_buf(ctx->genp);
+    free_buf(ctx->preview_u8);
     for (auto ev : ctx->events) (void)hipEventDestroy(ev);
     for (auto ev : ctx->depth_events) (void)hipEventDestroy(ev);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -692,6 +699,14 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl + 1], st));
         hipLaunchKernelGGL(k_resolve, dim3((npix + 255u) / 256u), dim3(256), 0, st, rad, acc, npix, sc);
         hipLaunchKernelGGL(k_accum_counts, dim3((unsigned)n_depths), dim3(256), 0, st, counts, nq, (uint32_t)n_depths, totals + 2);
+        if (ctx->progress_armed && ctx->progress_fn && sl + 1 < n_slices) { // the last slice is the final image itself
+            const uint32_t done = s0 + sc;
+            hipLaunchKernelGGL(k_finalize, dim3((npix + 255u) / 256u), dim3(256), 0, st, acc, (float*)nullptr,
+                               (uint8_t*)ctx->preview_u8.p, nx, rows, done);
+            RT_HIP(ctx, hipMemcpyAsync(ctx->preview_host.data(), ctx->preview_u8.p, (size_t)npix * 3, hipMemcpyDeviceToHost, st));
+            RT_HIP(ctx, hipStreamSynchronize(st));
+            ctx->progress_fn(ctx->progress_user, done, spp, ctx->preview_host.data(), nx, rows);
+        }
     }
     hipLaunchKernelGGL(k_finalize, dim3((npix + 255u) / 256u), dim3(256), 0, st, acc, (float*)d_out_rgb_f32,
                        (uint8_t*)d_out_rgb8, nx, rows, spp);
@@ -745,13 +760,26 @@ int rt_render(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, float* out_r
     if ((rc = ensure(ctx, ctx->out_f32, n * sizeof(float)))) return rc;
     // the u8 image is produced only on request
     if (out_rgb8 && (rc = ensure(ctx, ctx->out_u8, n))) return rc;
+    if (ctx->progress_fn) {
+        if ((rc = ensure(ctx, ctx->preview_u8, n))) return rc;
+        ctx->preview_host.resize(n);
+    }
     RtStats local;
+    ctx->progress_armed = true;
     rc = render_impl(ctx, cam, prm, ctx->out_f32.p, out_rgb8 ? ctx->out_u8.p : nullptr, nullptr, stats ? stats : &local);
+    ctx->progress_armed = false;
     if (rc) return rc;
     const auto w0 = std::chrono::steady_clock::now();
     if (out_rgb_f32 && n) RT_HIP(ctx, hipMemcpy(out_rgb_f32, ctx->out_f32.p, n * sizeof(float), hipMemcpyDeviceToHost));
     if (out_rgb8 && n) RT_HIP(ctx, hipMemcpy(out_rgb8, ctx->out_u8.p, n, hipMemcpyDeviceToHost));
     if (stats) stats->seconds_total += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    return RT_OK;
+}
+
+int rt_set_progress(RtCtx* ctx, RtProgressFn fn, void* user) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->progress_fn = fn;
+    ctx->progress_user = user;
     return RT_OK;
 }
 

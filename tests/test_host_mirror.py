@@ -191,3 +191,25 @@ def test_bvh_shape_decides_medium_visit_count(rt):
     s.set_camera((0, 0, 20), (0, 0, 0), (0, 1, 0), 40, 1.0)
     s.finish(use_bvh=False)                                              # a plain HitableList visits each object once
     assert s.arrays()["med_neg_inv_density"].tolist() == [-2.0, -2.0, -2.0]
+
+
+def test_png_writer_and_output_name(rt, tmp_path):
+    """main.rs:110-112,121,127-128: 8-bit RGB PNG with the pixels as given, and the time-stamped file name."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    path = tmp_path / "out.png"
+    rt.save_png(path, img)
+    back = Image.open(path)
+    assert back.mode == "RGB" and back.size == (53, 37)
+    assert np.array_equal(np.asarray(back), img)
+    assert not (tmp_path / "out.png.part").exists()
+    with pytest.raises(ValueError):
+        rt.save_png(path, img[:, :, 0])
+    import re
+    import time
+    name = rt.output_file_name()
+    assert re.fullmatch(r"\d{4}-\d{2}-\d{2}T\d{2}-\d{2}-\d{2}\.png", name)
+    t = 1715972624  # any fixed instant: the name is the local wall-clock time of it
+    lt = time.localtime(t)
+    assert rt.output_file_name(t) == time.strftime("%Y-%m-%dT%H-%M-%S.png", lt)
