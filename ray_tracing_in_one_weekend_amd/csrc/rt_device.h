@@ -112,6 +112,9 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Rng& rng) { // math.rs:17-37
         float z = rng.next();
         V3 v = v3(x, y, z) * (1.0f - -1.0f) + -1.0f;
         if (length_squared(v) < 1.0f) return v;
+#ifdef RT_EXP_ONE_ITER
+        return v; // experiment only (scripts/): cost of the rejection loop's divergence
+#endif
     }
 }
 __device__ __forceinline__ V3 random_on_hemisphere(Rng& rng, V3 n) { // math.rs:43-53
@@ -262,6 +265,9 @@ __device__ inline float perlin_noise(const PerlinTables& pt, uint32_t set, V3 p)
     return accum;
 }
 __device__ inline float perlin_turb(const PerlinTables& pt, uint32_t set, V3 p) { // texture.rs:115-124
+#ifdef RT_EXP_NO_TURB
+    return 0.5f + 0.0f * p.x; // experiment only (scripts/): cost of the 7-octave turbulence
+#endif
     float accum = 0.0f;
     float w = 1.0f;
     for (int it = 0; it < 7; ++it) {
