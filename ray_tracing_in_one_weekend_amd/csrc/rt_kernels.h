@@ -273,7 +273,9 @@ struct BvhLds {
 };
 
 // LDS_NODES = false: the tree and the primitive geometry stay in HBM (scenes whose tree does not fit the
-// 160 KB of LDS, e.g. final_scene's 3.4 k primitives); only the traversal stacks live in LDS.
+// 160 KB of LDS, e.g. final_scene's 3.4 k primitives); only the traversal stacks live in LDS.  Keeping the top
+// levels of the tree (breadth-first prefix, up to 270 of final_scene's 1 150 nodes) in the LDS that is left
+// was measured: no gain (node fetches from L2 are hidden by 8 waves/SIMD; leaf work dominates).
 template <int BLOCK, bool LDS_NODES>
 __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
     const uint32_t n_nodes = sc.n_bvh4_nodes, n_sph = sc.n_spheres;
@@ -611,7 +613,7 @@ struct ShadeParams {
 // PERLIN_LDS: the Perlin gradient and permutation tables (texture.rs:53-58; 4.75 KB per set) are
 // staged into LDS.
 #define RT_PERLIN_LDS_MAX_SETS 4u
-#define RT_SORT_N 1024u   // rays per counting sort (4 per thread)
+#define RT_SORT_N 1024u   // rays per counting sort (4 per thread); 2048/4096 measured the same, 8192 slower
 #define RT_NCLASS 64u
 __host__ __device__ inline size_t shade_lds_bytes(uint32_t n_spheres, uint32_t n_perlin_lds) {
     size_t b = 16u + RT_NCLASS * 4u * 2u + RT_SORT_N * 2u; // counter, histogram, offsets, permutation

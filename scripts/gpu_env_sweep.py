@@ -1,0 +1,37 @@
+"""Interleaved sweep of an upload-time environment knob in one process:
+python scripts/gpu_env_sweep.py <scene> <spp> <rounds> <ENV_NAME> v0 v1 ...   -> median device ms per value
+(the knob is read by rt_scene_upload, so every value gets its own context)"""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ray_tracing_in_one_weekend_amd as rt
+
+scene_name, spp, rounds, env = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+values = sys.argv[5:]
+rt.register_default_images()
+square = scene_name in ("cornell_box", "final_scene")
+scene = rt.Scene.build(scene_name, 1.0 if square else 16 / 9)
+rends = []
+for v in values:
+    os.environ[env] = v
+    r = rt.Renderer(0)
+    r.upload(scene)
+    rends.append(r)
+os.environ.pop(env, None)
+p = rt.make_params(1080 if square else 1920, 1080, spp, max_depth=50, flags=rt._ffi.FLAG_TIME_DEPTHS)
+res = {v: [] for v in values}
+ref = None
+for it in range(rounds + 1):
+    for v, r in zip(values, rends):
+        img, _, st = r.render(scene.camera, p)
+        a, b, n = r.depth_timings()
+        if ref is None:
+            ref = img.copy()
+        assert (img.view("uint32") == ref.view("uint32")).all(), f"{env}={v} changes the image"
+        if it:
+            res[v].append((st.seconds_device * 1e3, st.n_rays, a.sum(), b.sum()))
+for v in values:
+    t = statistics.median(x[0] for x in res[v])
+    print(f"{scene_name:14s} {env}={v:>6s}: {t:8.2f} ms  {res[v][0][1] / t / 1e3:8.0f} Mray/s  isect {statistics.median(x[2] for x in res[v]):7.2f} shade {statistics.median(x[3] for x in res[v]):7.2f}", flush=True)
