@@ -188,6 +188,10 @@ struct DevScene {
     const float* med_neg_inv_density;
     const uint2* med_range;
     const uint32_t* med_prims;
+    // world entries (BVH leaves): bounding sphere (xyz, r) and leaf id, for the primary-ray candidate lists
+    uint32_t n_entries;
+    const float4* ent_bs;
+    const uint32_t* ent_leaf;
     float bvh_exact_eps;       // slab slack above which a ray takes the cancellation-free test (2^-10 of the scene extent)
     const uint32_t* med_xform; // [n_media] wrapper chain shared by all boundary primitives, or RT_MED_XF_MIXED
     const uint32_t* prim_medium; // [n_prims] owning medium or 0xFFFFFFFF

@@ -44,6 +44,7 @@ struct GenParams {
     uint32_t shard_band, shard_count, shard_id;
     uint32_t nq, cap;
     uint32_t seed_lo, seed_hi;
+    const uint4* lists;   // per-pixel candidate lists of the primary rays (k_primary_lists) or NULL
 };
 
 __device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t band, uint32_t count, uint32_t id) {
@@ -53,9 +54,10 @@ __device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t
 
 // Primary ray of path `idx` of the slice (main.rs:86-94 + camera.rs:40-46).
 // idx = s_local * npix + pixel_local, so consecutive idx are consecutive pixels of a row.
-__device__ __forceinline__ void gen_primary(const GenParams& gp, uint32_t idx, V3& o, V3& d, uint32_t& k0, uint32_t& k1) {
+__device__ __forceinline__ void gen_primary(const GenParams& gp, uint32_t idx, V3& o, V3& d, uint32_t& k0, uint32_t& k1,
+                                            uint32_t& pl) {
     const uint32_t s_local = idx / gp.npix;
-    const uint32_t pl = idx - s_local * gp.npix;
+    pl = idx - s_local * gp.npix; // local pixel
     const uint32_t lj = pl / gp.nx;
     const uint32_t i = pl - lj * gp.nx;
     const uint32_t j = local_row_to_image_row(lj, gp.shard_band, gp.shard_count, gp.shard_id);
@@ -74,6 +76,10 @@ __device__ __forceinline__ void gen_primary(const GenParams& gp, uint32_t idx, V
     o = origin;
     d = normalize(llc + u * H + v * Vv - origin);
     k0 = rng.k0, k1 = rng.k1;
+}
+__device__ __forceinline__ void gen_primary(const GenParams& gp, uint32_t idx, V3& o, V3& d, uint32_t& k0, uint32_t& k1) {
+    uint32_t pl;
+    gen_primary(gp, idx, o, d, k0, k1, pl);
 }
 
 // Depth-0 queue geometry: chunks of 256 consecutive paths are dealt round-robin to the queue
@@ -112,6 +118,118 @@ __global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q) {
     q.a[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(idx));
     q.b[pos] = make_float4(d.x, d.y, d.z, __uint_as_float(k0));
     q.c[pos] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(k1));
+}
+
+// Candidate lists of the primary rays.  All samples of a pixel leave the camera through the pixel's footprint
+// (main.rs:89-90: u in [i/nx, (i+1)/nx], v likewise), i.e. inside a narrow cone around the ray through its
+// centre.  One lane per pixel tests that cone against the bounding sphere of every world entry and keeps the
+// entries it may touch: with 256 samples per pixel, depth 0 of every slice then tests ~2 listed primitives per
+// ray with the exact leaf code instead of walking the tree (k_intersect, GEN).  The test is conservative by
+// construction — cone half-angle from the four footprint corners widened by 2 % + 1e-4 rad, radii by 0.1 % —
+// so a list contains every entry any sample can hit, and the closest-hit rule does not depend on the order or
+// on extra candidates: same bits as the traversal.  More than 7 candidates: the pixel's rays use the tree.
+#define RT_LIST_MAX 7u
+#define RT_LIST_OVERFLOW 0xFFFFu
+#define RT_LIST_WAVE_CAP 512u // survivors of the wave-level cull kept per wave (more: the lanes scan all entries)
+// cone (axis, half-angle alpha given as sin/cos) against a bounding sphere seen from `origin`
+__device__ __forceinline__ bool cone_touches_sphere(V3 origin, V3 axis, float sa, float ca, float4 bs) {
+    const V3 c = v3(bs.x, bs.y, bs.z) - origin;
+    const float r = bs.w * 1.001f + 1e-6f;
+    const float dist2 = length_squared(c);
+    if (!(dist2 > r * r * 1.0001f)) return true; // the eye is inside or on the bounding sphere (or NaN)
+    const float dist = sqrtf(dist2);
+    const float sb = fminf(r / dist, 1.0f), cb = sqrtf(fmaxf(1.0f - sb * sb, 0.0f));
+    // theta = angle(axis, c) <= alpha + beta, beta = angular radius.  Both below 90 degrees (the usual case):
+    // compared through sines, |c x axis| = dist*sin(theta), which stays well-conditioned for the sub-milliradian
+    // angles of a pixel (cosines would need a slack of several pixels).  Otherwise through cosines, which are
+    // well-conditioned there.
+    const float c_theta = dot(c, axis);
+    const float c_sum = ca * cb - sa * sb, s_sum = sa * cb + ca * sb;
+    if (c_theta > 0.0f && c_sum > 0.0f) return length(cross(c, axis)) <= s_sum * dist * 1.0001f + 1e-6f * dist;
+    return c_theta >= c_sum * dist - 1e-5f * dist;
+}
+__global__ __launch_bounds__(256) void k_primary_lists(DevScene sc, GenParams gp, uint4* __restrict__ lists) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* s_bs = reinterpret_cast<float4*>(smem);
+    unsigned short* s_keep = reinterpret_cast<unsigned short*>(s_bs + sc.n_entries) + (threadIdx.x >> 6) * RT_LIST_WAVE_CAP;
+    for (uint32_t e = threadIdx.x; e < sc.n_entries; e += 256u) s_bs[e] = sc.ent_bs[e];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
+    const bool active = pl < gp.npix;
+    const uint32_t plc = active ? pl : gp.npix - 1u;
+    const uint32_t lj = plc / gp.nx;
+    const uint32_t i = plc - lj * gp.nx;
+    const uint32_t j = local_row_to_image_row(lj, gp.shard_band, gp.shard_count, gp.shard_id);
+    const V3 origin = v3(gp.cam_origin[0], gp.cam_origin[1], gp.cam_origin[2]);
+    const V3 H = v3(gp.cam_horizontal[0], gp.cam_horizontal[1], gp.cam_horizontal[2]);
+    const V3 Vv = v3(gp.cam_vertical[0], gp.cam_vertical[1], gp.cam_vertical[2]);
+    const V3 llc = v3(gp.cam_llc[0], gp.cam_llc[1], gp.cam_llc[2]);
+    const float u0 = (float)i / (float)gp.nx, u1 = ((float)i + 1.0f) / (float)gp.nx;
+    const float v0 = (float)j / (float)gp.ny, v1 = ((float)j + 1.0f) / (float)gp.ny;
+    const V3 axis = normalize(llc + (0.5f * (u0 + u1)) * H + (0.5f * (v0 + v1)) * Vv - origin);
+    // half-angle of the footprint cone through sines (|axis x corner|): a pixel spans ~1e-4 rad, far below the
+    // resolution of a cosine near 1
+    float smax = 0.0f;
+    smax = fmaxf(smax, length(cross(axis, normalize(llc + u0 * H + v0 * Vv - origin))));
+    smax = fmaxf(smax, length(cross(axis, normalize(llc + u1 * H + v0 * Vv - origin))));
+    smax = fmaxf(smax, length(cross(axis, normalize(llc + u0 * H + v1 * Vv - origin))));
+    smax = fmaxf(smax, length(cross(axis, normalize(llc + u1 * H + v1 * Vv - origin))));
+    const float alpha = asinf(fminf(smax, 1.0f)) * 1.02f + 1e-4f;
+    const float ca = cosf(alpha), sa = sinf(alpha);
+
+    // ---- wave-level cull: one cone around the 64 pixels of the wave (any 64: a row strip, a row wrap, rows of
+    // different shard bands), every lane tests 1/64 of the entries against it ------------------------------
+    V3 wsum = axis; // inactive lanes duplicate the last pixel: harmless for a bounding cone
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        wsum.x += __shfl_xor(wsum.x, off);
+        wsum.y += __shfl_xor(wsum.y, off);
+        wsum.z += __shfl_xor(wsum.z, off);
+    }
+    const V3 waxis = normalize(wsum);
+    // angle between the wave axis and this pixel's axis (through the sine when below 90 degrees), plus alpha
+    const float wc = dot(waxis, axis);
+    float wang = wc > 0.0f ? asinf(fminf(length(cross(waxis, axis)), 1.0f)) : 3.2f;
+    wang = wang * 1.001f + alpha;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wang = fmaxf(wang, __shfl_xor(wang, off));
+    const bool wide = !(wang < 1.5f); // a cone wider than ~86 degrees (or NaN): no cull
+    const float wca = cosf(wang), wsa = sinf(wang);
+    uint32_t n_keep = 0; // wave-uniform
+    bool scan_all = wide;
+    if (!wide) {
+        for (uint32_t e0 = 0; e0 < sc.n_entries; e0 += 64u) {
+            const uint32_t e = e0 + lane;
+            const bool keep = e < sc.n_entries && cone_touches_sphere(origin, waxis, wsa, wca, s_bs[e]);
+            const unsigned long long m = __ballot(keep);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            if (n_keep + cnt > RT_LIST_WAVE_CAP) {
+                scan_all = true;
+                break;
+            }
+            if (keep) s_keep[n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (unsigned short)e;
+            n_keep += cnt;
+        }
+    }
+    // ---- per pixel: the survivors (or everything) against the pixel's own cone, in entry order ---------------
+    uint32_t n = 0;
+    uint32_t ids[RT_LIST_MAX];
+#pragma unroll
+    for (uint32_t t = 0; t < RT_LIST_MAX; ++t) ids[t] = 0u;
+    const uint32_t n_scan = scan_all ? sc.n_entries : n_keep;
+    for (uint32_t t0 = 0; t0 < n_scan; ++t0) {
+        const uint32_t e = scan_all ? t0 : (uint32_t)s_keep[t0];
+        if (cone_touches_sphere(origin, axis, sa, ca, s_bs[e])) {
+#pragma unroll
+            for (uint32_t t = 0; t < RT_LIST_MAX; ++t)
+                if (n == t) ids[t] = sc.ent_leaf[e];
+            ++n;
+        }
+    }
+    if (!active) return;
+    const uint32_t head = n > RT_LIST_MAX ? RT_LIST_OVERFLOW : n;
+    lists[pl] = make_uint4(head | (ids[0] << 16), ids[1] | (ids[2] << 16), ids[3] | (ids[4] << 16), ids[5] | (ids[6] << 16));
 }
 
 // LDS tile of the sphere list: (cx, cy, cz, r) as float4, read by every lane at the same
@@ -310,6 +428,35 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
     return L;
 }
 
+// Exact test of world entry `s` (a BVH leaf or an entry of a primary-ray candidate list) and the order-independent
+// accept.  Sphere-only scenes: Sphere::hit roots (hitable.rs:75-91).
+template <bool RECTS>
+__device__ __forceinline__ void leaf_test(const BvhLds& L, int s, V3 o, V3 d, float a, uint32_t& pend, float& tbest,
+                                          int& hit) {
+    float th;
+    // candidate root of this primitive (independent of tbest), then the order-independent accept
+    bool ok;
+    if (!RECTS) {
+        ok = sphere_root(L.geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th);
+    } else {
+        // general scene: a primitive that may sit below Translate / RotateY wrappers (t is unchanged by
+        // them), or a medium.  A medium costs two searches over its boundary, ~12x a rectangle; tested
+        // here it would stall the lanes of the wave that are at cheap leaves on every step.  It is only
+        // noted in `pend` and tested after the traversal (media_step), when the lanes of the wave do so
+        // together.  The winner rule is order-independent, so the result is the same.
+        if ((uint32_t)s >= L.sc->n_prims) {
+            pend |= 1u << ((uint32_t)s - L.sc->n_prims);
+            ok = false;
+        } else {
+            ok = prim_root(*L.sc, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
+        }
+    }
+    if (ok && (th < tbest || (th == tbest && s > hit))) {
+        tbest = th;
+        hit = s;
+    }
+}
+
 // One traversal step of one lane.  `cur` >= 0: inner node — slab-test the 4 child boxes against
 // [0, tbest], continue with the nearest hit child, push the other hit children (unsorted: the visit
 // count is the same as with a full sort, 7.32 vs 7.29 node visits per ray on sphere_scene; a binary
@@ -384,29 +531,7 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
             return false;
         }
     } else {
-        const int s = ~cur;
-        float th;
-        // candidate root of this primitive (independent of tbest), then the order-independent accept
-        bool ok;
-        if (!RECTS) {
-            ok = sphere_root(L.geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th);
-        } else {
-            // general scene: a primitive that may sit below Translate / RotateY wrappers (t is unchanged by
-            // them), or a medium.  A medium costs two searches over its boundary, ~12x a rectangle; tested
-            // here it would stall the lanes of the wave that are at cheap leaves on every step.  It is only
-            // noted in `pend` and tested after the traversal (media_step), when the lanes of the wave do so
-            // together.  The winner rule is order-independent, so the result is the same.
-            if ((uint32_t)s >= L.sc->n_prims) {
-                pend |= 1u << ((uint32_t)s - L.sc->n_prims);
-                ok = false;
-            } else {
-                ok = prim_root(*L.sc, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
-            }
-        }
-        if (ok && (th < tbest || (th == tbest && s > hit))) {
-            tbest = th;
-            hit = s;
-        }
+        leaf_test<RECTS>(L, ~cur, o, d, a, pend, tbest, hit);
     }
     if (sp == 0) return true;
     --sp;
@@ -494,10 +619,12 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) off = (k == t) ? v - pre[t] : off;
                 const uint32_t shard = blockIdx.x + k * gridDim.x;
                 pos = (size_t)shard * ip.cap + off;
+                uint4 list = make_uint4(RT_LIST_OVERFLOW, 0u, 0u, 0u);
                 if (GEN) {
-                    uint32_t k0, k1;
-                    gen_primary(*gpd, primary_idx_of(ip.nq, shard, off), o, d, k0, k1);
+                    uint32_t k0, k1, pl;
+                    gen_primary(*gpd, primary_idx_of(ip.nq, shard, off), o, d, k0, k1, pl);
                     if (RECTS) mc.k0 = k0, mc.k1 = k1;
+                    if (gpd->lists) list = gpd->lists[pl];
                 } else {
                     const float4 ra = qa[pos], rb = qb[pos];
                     o = v3(ra.x, ra.y, ra.z);
@@ -518,6 +645,23 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 trav = true;
                 pend = 0u;
                 if (no_geometry) qh[pos] = make_float2(RT_FLT_MAX, __int_as_float(-1));
+                if (GEN && has && (list.x & 0xFFFFu) != RT_LIST_OVERFLOW) {
+                    // primary ray of a pixel with a candidate list (k_primary_lists): the listed entries instead of the tree
+                    const uint32_t n_list = list.x & 0xFFFFu;
+                    if (n_list > 0u) leaf_test<RECTS>(L, (int)(list.x >> 16), o, d, a, pend, tbest, hit);
+                    if (n_list > 1u) leaf_test<RECTS>(L, (int)(list.y & 0xFFFFu), o, d, a, pend, tbest, hit);
+                    if (n_list > 2u) leaf_test<RECTS>(L, (int)(list.y >> 16), o, d, a, pend, tbest, hit);
+                    if (n_list > 3u) leaf_test<RECTS>(L, (int)(list.z & 0xFFFFu), o, d, a, pend, tbest, hit);
+                    if (n_list > 4u) leaf_test<RECTS>(L, (int)(list.z >> 16), o, d, a, pend, tbest, hit);
+                    if (n_list > 5u) leaf_test<RECTS>(L, (int)(list.w & 0xFFFFu), o, d, a, pend, tbest, hit);
+                    if (n_list > 6u) leaf_test<RECTS>(L, (int)(list.w >> 16), o, d, a, pend, tbest, hit);
+                    if (RECTS && pend) {
+                        trav = false; // its media are tested in the media phase below
+                    } else {
+                        qh[pos] = make_float2(tbest, __int_as_float(hit));
+                        has = false;
+                    }
+                }
             }
         }
         if (!__any(has)) {

@@ -1,6 +1,7 @@
-"""Interleaved sweep of an upload-time environment knob in one process:
+"""Interleaved sweep of an environment knob in one process:
 python scripts/gpu_env_sweep.py <scene> <spp> <rounds> <ENV_NAME> v0 v1 ...   -> median device ms per value
-(the knob is read by rt_scene_upload, so every value gets its own context)"""
+Every value gets its own context (knobs read by rt_scene_upload) and the variable is also set around each render
+(knobs read by rt_render); the value "-" means unset."""
 import os
 import statistics
 import sys
@@ -14,8 +15,15 @@ rt.register_default_images()
 square = scene_name in ("cornell_box", "final_scene")
 scene = rt.Scene.build(scene_name, 1.0 if square else 16 / 9)
 rends = []
+def setenv(v):
+    if v == "-":
+        os.environ.pop(env, None)
+    else:
+        os.environ[env] = v
+
+
 for v in values:
-    os.environ[env] = v
+    setenv(v)
     r = rt.Renderer(0)
     r.upload(scene)
     rends.append(r)
@@ -25,7 +33,9 @@ res = {v: [] for v in values}
 ref = None
 for it in range(rounds + 1):
     for v, r in zip(values, rends):
+        setenv(v)
         img, _, st = r.render(scene.camera, p)
+        os.environ.pop(env, None)
         a, b, n = r.depth_timings()
         if ref is None:
             ref = img.copy()

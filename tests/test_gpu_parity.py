@@ -649,3 +649,47 @@ def test_progressive_preview_and_driver(rt, renderer, tmp_path):
     assert driver.main(["--scene", "test_sphere", "--nx", "160", "--ny", "80", "--spp", "12", "--preview-every", "4",
                         "--out", str(out)]) == 0
     assert np.array_equal(np.asarray(Image.open(out)), ref8)
+
+
+@pytest.mark.gpu
+def test_primary_candidate_lists_do_not_change_images(rt, renderer, monkeypatch):
+    """k_primary_lists: depth 0 tests the entries listed for the pixel instead of walking the tree.  The lists are
+    conservative and the closest-hit rule is order-independent, so frames are bit-identical with and without them —
+    on every mirrored scene, for a sharded frame, and with the eye inside a primitive's bounding sphere."""
+    cases = [("sphere_scene", 16 / 9, 320, 180), ("simple_light_scene", 16 / 9, 320, 180), ("cornell_box", 1.0, 200, 200),
+             ("final_scene", 1.0, 200, 200), ("earth_env_scene", 16 / 9, 320, 180), ("pbr_sweep_scene", 16 / 9, 320, 180)]
+    for name, aspect, nx, ny in cases:
+        scene = rt.Scene.build(name, aspect)
+        renderer.upload(scene)
+        p = rt.make_params(nx, ny, 8, max_depth=12)
+        a, _, sa = renderer.render(scene.camera, p)
+        monkeypatch.setenv("RTOW_NO_PRIMARY_LISTS", "1")
+        b, _, sb = renderer.render(scene.camera, p)
+        monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS")
+        assert int(sa.n_rays) == int(sb.n_rays), name
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+    # sharded rows use local pixel indices for the lists
+    scene = rt.Scene.build("sphere_scene", 16 / 9)
+    renderer.upload(scene)
+    full, _, _ = renderer.render(scene.camera, rt.make_params(320, 180, 8, max_depth=12))
+    from ray_tracing_in_one_weekend_amd import shard
+    parts = [renderer.render(scene.camera, rt.make_params(320, 180, 8, max_depth=12, shard_band=8, shard_count=3, shard_id=r))[0]
+             for r in range(3)]
+    assert np.array_equal(shard.deinterleave(parts, 180, 8, 3).view(np.uint32), full.view(np.uint32))
+    # the eye inside a glass ball, a wall of small spheres behind it (many candidates per pixel -> overflow -> tree)
+    s = rt.Scene.new()
+    glass = s.material(rt._ffi.MAT_DIELECTRIC, p=(1.5, 0, 0, 0))
+    red = s.material(rt._ffi.MAT_DIFFUSE, tex0=s.constant_tex((0.8, 0.2, 0.2)))
+    s.sphere((0, 0, 0), 2.0, glass, "around the eye")
+    rng = np.random.default_rng(5)
+    for c in rng.uniform(-3, 3, size=(300, 2)):
+        s.sphere((float(c[0]), float(c[1]), -8.0 - float(rng.uniform(0, 4))), 0.5, red, "wall")
+    s.set_camera((0, 0, 0.5), (0, 0, -8), (0, 1, 0), 40, 1.5)
+    s.finish()
+    renderer.upload(s)
+    p = rt.make_params(150, 100, 8, max_depth=8)
+    a, _, _ = renderer.render(s.camera, p)
+    monkeypatch.setenv("RTOW_NO_PRIMARY_LISTS", "1")
+    b, _, _ = renderer.render(s.camera, p)
+    monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS")
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.std() > 0.01
