@@ -49,6 +49,27 @@ def pmc_traffic(workload_key):
     return t["trace_step_bytes_per_launch"], os.path.relpath(p, ROOT)
 
 
+def pmc_valu(workload_key):
+    """VALU issue fraction / lane utilisation of the trace kernels from the committed PMC pass of this same command
+    (scripts/collect_valu.py); None when absent or for another workload."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "valu*.json"))):
+        try:
+            t = json.load(open(p))
+        except (OSError, ValueError):
+            continue
+        if (t.get("bench_config") or {}).get("workload") == workload_key:
+            best = (p, t)
+    if not best:
+        return None
+    p, t = best
+    out = {k: {"issue_frac": round(v["issue_frac"], 4), "lane_util": round(v["lane_util"], 4)} for k, v in t["kernels"].items()}
+    out["source"] = os.path.relpath(p, ROOT)
+    out["note"] = "the bound that limits this path: VALU issue slots used / available (1024 SIMDs, 4 cycles per wave64 instruction, 2.4 GHz)"
+    return out
+
+
 def usable_cores():
     """Host cores this process may actually use: the cgroup CPU quota (cpu.max) caps the GPU box's
     share well below os.cpu_count(), and oversubscribing the quota only adds throttling."""
@@ -217,6 +238,7 @@ def main():
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "valu": pmc_valu(workload),
                          "bytes_per_launch": round(trace_bytes / max(launches, 1), 1),
                          "avg_launch_us": round(trace_s / max(launches, 1) * 1e6, 3),
                          "launches": launches,
