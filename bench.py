@@ -66,7 +66,8 @@ def pmc_valu(workload_key):
     p, t = best
     out = {k: {"issue_frac": round(v["issue_frac"], 4), "lane_util": round(v["lane_util"], 4)} for k, v in t["kernels"].items()}
     out["source"] = os.path.relpath(p, ROOT)
-    out["note"] = "the bound that limits this path: VALU issue slots used / available (1024 SIMDs, 4 cycles per wave64 instruction, 2.4 GHz)"
+    out["note"] = ("the bound that limits this path: VALU issue slots used / available (1024 SIMDs, 4 cycles per wave64 "
+                   "instruction, 2.4 GHz; > 1 = saturated, see the source file's note); lane_util = active lanes per issued instruction")
     return out
 
 
