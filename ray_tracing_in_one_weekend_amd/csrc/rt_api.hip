@@ -50,6 +50,7 @@ struct RtCtx {
     bool use_bvh = false;      // scene BVH fits LDS next to the traversal stacks
     size_t isect_lds = 0;      // k_intersect: nodes + geometry (when they fit) + stack levels + counters
     bool bvh_in_lds = false;   // false: the tree is traversed out of HBM/L2, only the stacks are in LDS
+    bool general_lds = false;  // k_intersect<.., GLDS>: the wrapper / medium tables of a general scene are staged in LDS
     // progressive preview (rt_set_progress): called from rt_render after every slice
     RtProgressFn progress_fn = nullptr;
     void* progress_user = nullptr;
@@ -479,6 +480,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     ds.n_prims = n_prims;
     ds.n_bvh4_nodes = (uint32_t)bvh4.id.size();
     ds.n_entries = (uint32_t)eboxes.size();
+    ds.n_med_prims = (uint32_t)med_prims.size();
     {   // rays whose slab slack exceeds 2^-10 of the scene extent use the cancellation-free slab test (bvh_step)
         double ext2 = 0.0;
         for (int k = 0; k < 3; ++k) {
@@ -520,14 +522,25 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
                       !(force_hbm && force_hbm[0] == '1');
     ctx->isect_lds = bvh_lds_bytes(ds, RT_BVH_BLOCK, ctx->bvh_in_lds);
     ctx->use_bvh = bvh_ok && ctx->isect_lds <= ctx->lds_limit;
+    // general scenes: wrapper / medium tables behind the tree carve, when two workgroups per CU still fit
+    ctx->general_lds = false;
+    if (ctx->use_bvh && (ds.n_xforms || ds.n_media) && ctx->isect_lds + general_lds_bytes(ds) <= ctx->lds_limit / 2 &&
+        !getenv("RTOW_NO_GENERAL_LDS")) {
+        ctx->isect_lds += general_lds_bytes(ds);
+        ctx->general_lds = true;
+    }
     if (ctx->use_bvh) {
         const void* variants[] = {
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, false, true>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, true>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, false, true>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, true>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, false>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, false>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, false, true, false>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, true, false>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, false, true, false>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, true, false>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, false, false>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, false, false>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, true, true>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, true, true>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, false, true>),
+            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, false, true>),
             reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, true>),
             reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, false>)};
         for (const void* fn : variants)
@@ -682,16 +695,22 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth], st));
             const bool gen = fuse_gen && depth == 0;
             ip.depth = depth;
-#define RT_LAUNCH_ISECT(G, R, N)                                                                                       \
-    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R, N>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, \
+#define RT_LAUNCH_ISECT(G, R, N, T)                                                                                    \
+    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R, N, T>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, \
                        qi.a, qi.b, qi.c, qhit, cin, ip, gpd)
+#define RT_LAUNCH_ISECT_G(G, N)                       \
+    do {                                              \
+        if (ctx->general_lds) RT_LAUNCH_ISECT(G, true, N, true); \
+        else RT_LAUNCH_ISECT(G, true, N, false);      \
+    } while (0)
             // trees that do not fit LDS use the general instantiation (R = true works for sphere-only scenes too)
-            if (use_bvh && !ctx->bvh_in_lds && gen) RT_LAUNCH_ISECT(true, true, false);
-            else if (use_bvh && !ctx->bvh_in_lds) RT_LAUNCH_ISECT(false, true, false);
-            else if (use_bvh && gen && rects) RT_LAUNCH_ISECT(true, true, true);
-            else if (use_bvh && gen) RT_LAUNCH_ISECT(true, false, true);
-            else if (use_bvh && rects) RT_LAUNCH_ISECT(false, true, true);
-            else if (use_bvh) RT_LAUNCH_ISECT(false, false, true);
+            if (use_bvh && !ctx->bvh_in_lds && gen) RT_LAUNCH_ISECT_G(true, false);
+            else if (use_bvh && !ctx->bvh_in_lds) RT_LAUNCH_ISECT_G(false, false);
+            else if (use_bvh && gen && rects) RT_LAUNCH_ISECT_G(true, true);
+            else if (use_bvh && gen) RT_LAUNCH_ISECT(true, false, true, false);
+            else if (use_bvh && rects) RT_LAUNCH_ISECT_G(false, true);
+            else if (use_bvh) RT_LAUNCH_ISECT(false, false, true, false);
+#undef RT_LAUNCH_ISECT_G
 #undef RT_LAUNCH_ISECT
             else
                 hipLaunchKernelGGL(k_intersect_list, dim3(nq), dim3(256), list_lds, st, ctx->ds, qi.a, qi.b, qi.c, qhit, cin, ip);

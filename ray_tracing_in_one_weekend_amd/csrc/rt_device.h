@@ -188,6 +188,7 @@ struct DevScene {
     const float* med_neg_inv_density;
     const uint2* med_range;
     const uint32_t* med_prims;
+    uint32_t n_med_prims;      // total length of med_prims
     // world entries (BVH leaves): bounding sphere (xyz, r) and leaf id, for the primary-ray candidate lists
     uint32_t n_entries;
     const float4* ent_bs;
@@ -448,7 +449,9 @@ struct Chain {
     uint32_t id[RT_MAX_CHAIN]; // id[0] = innermost wrapper ... id[n-1] = outermost
     int n;
 };
-__device__ __forceinline__ Chain load_chain(const DevScene& sc, uint32_t xf) {
+// (templates over the table holder: DevScene, or the GenTables view of rt_kernels.h whose tables live in LDS)
+template <class Tables>
+__device__ __forceinline__ Chain load_chain(const Tables& sc, uint32_t xf) {
     Chain c;
     c.n = 0;
 #pragma unroll
@@ -463,7 +466,8 @@ __device__ __forceinline__ Chain load_chain(const DevScene& sc, uint32_t xf) {
 }
 // The ray a wrapper hands to its child: Translate moves the origin (hitable.rs:411), RotateY rotates origin
 // and direction (hitable.rs:483-492).
-__device__ __forceinline__ void xform_ray(const DevScene& sc, uint32_t x, V3& o, V3& d) {
+template <class Tables>
+__device__ __forceinline__ void xform_ray(const Tables& sc, uint32_t x, V3& o, V3& d) {
     const float4 q = sc.xf_param[x];
     if (sc.xf_meta[x].x == 0u) {
         o = o - v3(q.x, q.y, q.z);
@@ -475,7 +479,8 @@ __device__ __forceinline__ void xform_ray(const DevScene& sc, uint32_t x, V3& o,
     }
 }
 // world ray -> the ray the primitive itself is tested with (outermost wrapper first)
-__device__ __forceinline__ void chain_to_object(const DevScene& sc, const Chain& c, V3& o, V3& d) {
+template <class Tables>
+__device__ __forceinline__ void chain_to_object(const Tables& sc, const Chain& c, V3& o, V3& d) {
 #pragma unroll
     for (int k = RT_MAX_CHAIN - 1; k >= 0; --k)
         if (k < c.n) xform_ray(sc, c.id[k], o, d);

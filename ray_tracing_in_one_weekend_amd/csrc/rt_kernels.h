@@ -255,7 +255,8 @@ struct MediumCtx {
 };
 // Candidate root of one geometric primitive through its wrapper chain (general scenes), geometry from `geo`
 // (spheres, then 2 float4 per rectangle; LDS in k_intersect, HBM in the list walk).
-__device__ __forceinline__ bool prim_root(const DevScene& sc, const float4* geo, uint32_t s, V3 o, V3 d, float t_min,
+template <class Tables>
+__device__ __forceinline__ bool prim_root(const Tables& sc, const float4* geo, uint32_t s, V3 o, V3 d, float t_min,
                                           float t_max, float& th) {
     const uint32_t xf = sc.prim_xform[s];
     if (xf != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, xf), o, d);
@@ -265,8 +266,8 @@ __device__ __forceinline__ bool prim_root(const DevScene& sc, const float4* geo,
 }
 // Root of one boundary primitive for a ray that is already in the object space of the medium's common chain
 // (RAW) or still in world space (the primitive applies its own chain).
-template <bool RAW>
-__device__ __forceinline__ bool boundary_prim_root(const DevScene& sc, const float4* geo, uint32_t s, V3 o, V3 d,
+template <bool RAW, class Tables>
+__device__ __forceinline__ bool boundary_prim_root(const Tables& sc, const float4* geo, uint32_t s, V3 o, V3 d,
                                                    float t_min, float t_max, float& th) {
     if (!RAW) return prim_root(sc, geo, s, o, d, t_min, t_max, th);
     if (s < sc.n_spheres) return sphere_root(geo[s], o, d, length_squared(d), t_min, t_max, th);
@@ -274,8 +275,8 @@ __device__ __forceinline__ bool boundary_prim_root(const DevScene& sc, const flo
     return rect_root(geo[gi], geo[gi + 1u], o, d, t_min, t_max, th);
 }
 // boundary.hit(r, t_min, t_max): closest accepted root over the medium's boundary primitives
-template <bool RAW>
-__device__ __forceinline__ bool boundary_root(const DevScene& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
+template <bool RAW, class Tables>
+__device__ __forceinline__ bool boundary_root(const Tables& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
                                               float t_max, float& t_out) {
     const uint2 rg = sc.med_range[m];
     bool any = false;
@@ -298,7 +299,8 @@ __device__ __forceinline__ bool boundary_root(const DevScene& sc, const float4* 
 // cannot win and the second boundary search is skipped (pure culling, no effect on the result).
 // When all boundary primitives sit below the same wrapper chain (a GBox under RotateY/Translate) the ray is
 // moved to object space once instead of once per primitive and search — the same bits either way.
-__device__ __forceinline__ bool medium_root(const DevScene& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
+template <class Tables>
+__device__ __forceinline__ bool medium_root(const Tables& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
                                             float t_max, float t_cull, const MediumCtx& mc, float& t_hit) {
     float t1, t2;
     const float ray_len = length(d); // of the world-space ray, hitable.rs:560
@@ -381,12 +383,49 @@ __host__ __device__ inline size_t bvh_lds_bytes(const DevScene& sc, uint32_t blo
            (size_t)block * bvh_stack_levels(sc) * 2u + 16u;
 }
 
+// The small tables a leaf test of a general scene walks through: prim_xform -> xf_meta parent links -> xf_param is
+// up to five DEPENDENT loads before the geometry is touched, and a medium adds its range / primitive list.  Read
+// from HBM/L2 those round trips were most of a leaf's cost on final_scene's cloud of 1 000 instanced spheres;
+// k_intersect<.., GLDS> copies them into LDS and traverses with a view that points at the copies.
+struct GenTables {
+    const float4* xf_param;
+    const uint2* xf_meta;
+    const uint32_t* prim_xform;
+    const uint2* med_range;
+    const uint32_t* med_prims;
+    const uint32_t* med_xform;
+    const float* med_neg_inv_density;
+    uint32_t n_spheres, n_prims;
+};
+__device__ __forceinline__ GenTables tables_of(const DevScene& sc) {
+    return GenTables{sc.xf_param, sc.xf_meta, sc.prim_xform, sc.med_range, sc.med_prims, sc.med_xform, sc.med_neg_inv_density,
+                     sc.n_spheres, sc.n_prims};
+}
+__host__ __device__ inline size_t general_lds_bytes(const DevScene& sc) {
+    return ((size_t)sc.n_xforms * 24u + (size_t)sc.n_prims * 4u + (size_t)sc.n_media * 16u + (size_t)sc.n_med_prims * 4u + 31u) & ~(size_t)15u;
+}
+template <int BLOCK>
+__device__ __forceinline__ GenTables stage_general(const DevScene& sc, char* smem) {
+    float4* xp = reinterpret_cast<float4*>(smem);
+    uint2* xm = reinterpret_cast<uint2*>(xp + sc.n_xforms);
+    uint2* mr = xm + sc.n_xforms;
+    uint32_t* px = reinterpret_cast<uint32_t*>(mr + sc.n_media);
+    uint32_t* mp = px + sc.n_prims;
+    uint32_t* mx = mp + sc.n_med_prims;
+    float* md = reinterpret_cast<float*>(mx + sc.n_media);
+    for (uint32_t i = threadIdx.x; i < sc.n_xforms; i += BLOCK) xp[i] = sc.xf_param[i], xm[i] = sc.xf_meta[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_media; i += BLOCK) mr[i] = sc.med_range[i], mx[i] = sc.med_xform[i], md[i] = sc.med_neg_inv_density[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_prims; i += BLOCK) px[i] = sc.prim_xform[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_med_prims; i += BLOCK) mp[i] = sc.med_prims[i];
+    return GenTables{xp, xm, px, mr, mp, mx, md, sc.n_spheres, sc.n_prims};
+}
+
 struct BvhLds {
     const float4* pl[6]; // min_x, min_y, min_z, max_x, max_y, max_z of the 4 children
     const int4* id;
     const float4* geo;     // spheres (1 float4 each), then rectangles (2 float4 each)
     uint32_t n_spheres;
-    const DevScene* sc;    // wrapper tables of general scenes (HBM)
+    GenTables gt;          // wrapper / medium tables of general scenes (HBM, or LDS with GLDS)
     unsigned short* stack; // this lane's column: stack[level * BLOCK]
 };
 
@@ -405,7 +444,7 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
         L.id = sc.bvh4_id;
         L.geo = sc.prim_geo;
         L.n_spheres = n_sph;
-        L.sc = &sc;
+        L.gt = tables_of(sc);
         L.stack = reinterpret_cast<unsigned short*>(smem) + threadIdx.x;
         return L;
     }
@@ -423,7 +462,7 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
     L.id = ids;
     L.geo = geo;
     L.n_spheres = n_sph;
-    L.sc = &sc;
+    L.gt = tables_of(sc);
     L.stack = reinterpret_cast<unsigned short*>(geo + n_sph + 2u * sc.n_rects) + threadIdx.x;
     return L;
 }
@@ -444,11 +483,11 @@ __device__ __forceinline__ void leaf_test(const BvhLds& L, int s, V3 o, V3 d, fl
         // here it would stall the lanes of the wave that are at cheap leaves on every step.  It is only
         // noted in `pend` and tested after the traversal (media_step), when the lanes of the wave do so
         // together.  The winner rule is order-independent, so the result is the same.
-        if ((uint32_t)s >= L.sc->n_prims) {
-            pend |= 1u << ((uint32_t)s - L.sc->n_prims);
+        if ((uint32_t)s >= L.gt.n_prims) {
+            pend |= 1u << ((uint32_t)s - L.gt.n_prims);
             ok = false;
         } else {
-            ok = prim_root(*L.sc, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
+            ok = prim_root(L.gt, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
         }
     }
     if (ok && (th < tbest || (th == tbest && s > hit))) {
@@ -543,9 +582,9 @@ __device__ __forceinline__ bool media_step(const BvhLds& L, V3 o, V3 d, const Me
                                            int& hit) {
     const uint32_t m = (uint32_t)__ffs((int)pend) - 1u;
     pend &= pend - 1u;
-    const int s = (int)(L.sc->n_prims + m);
+    const int s = (int)(L.gt.n_prims + m);
     float th;
-    if (medium_root(*L.sc, L.geo, m, o, d, 1e-3f, RT_FLT_MAX, tbest, mc, th) && (th < tbest || (th == tbest && s > hit))) {
+    if (medium_root(L.gt, L.geo, m, o, d, 1e-3f, RT_FLT_MAX, tbest, mc, th) && (th < tbest || (th == tbest && s > hit))) {
         tbest = th;
         hit = s;
     }
@@ -565,7 +604,7 @@ struct IntersectParams {
 // 1024-thread workgroups (8 waves per SIMD) share a CU and hide each other's dependent node fetches
 // — measured +15 % on cornell_box and +20 % on final_scene against 7 waves = one workgroup.
 // GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
-template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES>
+template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES, bool GLDS>
 __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float4* __restrict__ qa,
                                                      const float4* __restrict__ qb, const float4* __restrict__ qc,
                                                      float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
@@ -584,7 +623,8 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
     }
     const uint32_t total = pre[RT_ISECT_MAX_SHARDS];
     if (total == 0) return; // block-uniform
-    const BvhLds L = stage_bvh<BLOCK, LDS_NODES>(sc, smem);
+    BvhLds L = stage_bvh<BLOCK, LDS_NODES>(sc, smem);
+    if (GLDS) L.gt = stage_general<BLOCK>(sc, smem + bvh_lds_bytes(sc, BLOCK, LDS_NODES));
     uint32_t* s_work = reinterpret_cast<uint32_t*>(smem + bvh_lds_bytes(sc, BLOCK, LDS_NODES) - 16u);
     if (threadIdx.x == 0) *s_work = 0u;
     __syncthreads();
