@@ -578,10 +578,21 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         return RT_OK;
     }
     const uint32_t npix = (uint32_t)npix64;
-    // slice size: bound the ray queue to ~256 Mi rays (28 GiB of queues out of 288 GB HBM): few, large
-    // slices amortise the short-queue tail of the bounce loop (depths > ~12 hold a few thousand rays)
+    // slice size: few, large slices amortise the short-queue tail of the bounce loop (depths > ~12 hold a few
+    // thousand rays) — config 2 measured 99 / 88 / 82 / 79.5 ms per frame with 8 / 4 / 2 / 1 slices.  A ray of
+    // the slice costs 116 B of work buffers (two 48 B queues, 8 B hit record, 12 B radiance slot): up to 640 Mi
+    // rays (74 GiB of the 288 GB HBM), less when the device has less memory to give.
     uint32_t S = prm->spp_slice;
-    if (S == 0) S = (uint32_t)std::max<uint64_t>(1, (256ull << 20) / npix64);
+    if (S == 0) {
+        uint64_t max_rays = 640ull << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            size_t held = ctx->rad.bytes + ctx->qhit.bytes;
+            for (const DevBuf& b : ctx->qbuf) held += b.bytes;
+            max_rays = std::min<uint64_t>(max_rays, (uint64_t)((double)(free_b + held) * 0.5 / 116.0));
+        }
+        S = (uint32_t)std::max<uint64_t>(1, max_rays / npix64);
+    }
     S = std::min(S, spp);
     if ((uint64_t)S * npix64 > 0xFFFFFF00ull) S = (uint32_t)(0xFFFFFF00ull / npix64);
     if (S == 0) return fail(ctx, RT_ERR_UNSUPPORTED, "render: shard has more than 2^32 pixels");

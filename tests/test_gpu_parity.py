@@ -708,7 +708,7 @@ def test_config2_full_size_three_searches_agree(rt, renderer, monkeypatch):
     b, _, sb = renderer.render(scene.camera, p)
     monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS")
     c, _, sc = renderer.render(scene.camera, rt.make_params(1920, 1080, 256, max_depth=50, flags=rt._ffi.FLAG_BRUTE_FORCE))
-    assert sa.n_paths == 1920 * 1080 * 256 and sa.n_slices == 2
+    assert sa.n_paths == 1920 * 1080 * 256 and sa.n_slices in (1, 2)  # one slice when HBM has 62 GB to give
     assert np.array_equal(a.view(np.uint32), c.view(np.uint32)) and np.array_equal(b.view(np.uint32), c.view(np.uint32))
     assert sa.rays_per_depth[1] == sc.rays_per_depth[1]          # primary rays: lists == list walk
     assert abs(int(sb.n_rays) - int(sc.n_rays)) <= 8 and abs(int(sa.n_rays) - int(sc.n_rays)) <= 8
