@@ -371,10 +371,33 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         xparam[i] = make_float4(s->xf_param[4 * i], s->xf_param[4 * i + 1], s->xf_param[4 * i + 2], s->xf_param[4 * i + 3]);
         xmeta[i] = make_uint2(s->xf_type[i], s->xf_parent[i]);
     }
+    std::vector<float4> world_sphere(s->n_spheres); // instanced spheres: centre and radius in world space (culling only)
     for (uint32_t i = 0; i < n_prims; ++i) {
         const uint32_t x0 = i < s->n_spheres ? (s->sph_xform ? s->sph_xform[i] : RT_NO_XFORM)
                                              : (s->rect_xform ? s->rect_xform[i - s->n_spheres] : RT_NO_XFORM);
         pxf[i] = x0;
+        if (i < s->n_spheres && x0 != RT_NO_XFORM) {
+            // A sphere below Translate / RotateY wrappers is still a sphere: its world box is centre' +- r, not the
+            // box of the rotated box that RotateY::new computes (22 % wider per axis at 15 degrees, and the cloud of
+            // final_scene is 1 000 overlapping instanced spheres).  The exact test runs in object space on a ray
+            // whose transform rounds at the magnitude of the WORLD coordinates, so the box gets that slack.
+            double c[3] = {geo[i].x, geo[i].y, geo[i].z}, mag = std::fabs(geo[i].w);
+            for (uint32_t x = x0; x != RT_NO_XFORM; x = s->xf_parent[x]) {
+                const float* q = s->xf_param + 4 * (size_t)x;
+                for (int k = 0; k < 3; ++k) mag = std::max(mag, std::fabs(c[k]));
+                if (s->xf_type[x] == RT_XF_TRANSLATE) {
+                    for (int k = 0; k < 3; ++k) c[k] += (double)q[k];
+                } else {
+                    const double sn = q[0], cs = q[1], cx = c[0], cz = c[2];
+                    c[0] = cs * cx + sn * cz, c[2] = -sn * cx + cs * cz;
+                }
+                for (int k = 0; k < 3; ++k) mag = std::max(mag, std::fabs(c[k]));
+            }
+            const double r = std::fabs((double)geo[i].w), slack = 8e-6 * mag + 1e-30;
+            for (int k = 0; k < 3; ++k) pboxes[i].mn[k] = (float)(c[k] - r - slack), pboxes[i].mx[k] = (float)(c[k] + r + slack);
+            world_sphere[i] = make_float4((float)c[0], (float)c[1], (float)c[2], (float)(r + 2.0 * slack));
+            continue;
+        }
         for (uint32_t x = x0; x != RT_NO_XFORM; x = s->xf_parent[x]) {
             PrimBox& b = pboxes[i];
             const float* q = s->xf_param + 4 * (size_t)x;
@@ -435,6 +458,8 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         const uint32_t id = entry_ids[e];
         if (id < s->n_spheres && pxf[id] == RT_NO_XFORM) {
             ent_bs[e] = make_float4(s->sph_cx[id], s->sph_cy[id], s->sph_cz[id], std::fabs(s->sph_r[id]));
+        } else if (id < s->n_spheres) {
+            ent_bs[e] = world_sphere[id];
         } else {
             const PrimBox& b = eboxes[e];
             const double hx = 0.5 * ((double)b.mx[0] - b.mn[0]), hy = 0.5 * ((double)b.mx[1] - b.mn[1]), hz = 0.5 * ((double)b.mx[2] - b.mn[2]);
