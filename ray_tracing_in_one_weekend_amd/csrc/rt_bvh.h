@@ -227,6 +227,13 @@ inline int collapse4(const HostBvh& b, int n, HostBvh4& o, uint32_t depth) {
             add(cmn[k], cmx[k], ch[k]);
         }
     }
+    // leaves first: sphere-only scenes test a leaf child inside the node step (rt_kernels.h), and a hit there
+    // tightens the limit the inner children that follow are culled against
+    for (int i = 1; i < cnt; ++i)
+        for (int j = i; j > 0 && cid[j] < 0 && cid[j - 1] >= 0; --j) {
+            std::swap(cid[j], cid[j - 1]);
+            for (int k = 0; k < 3; ++k) std::swap(mn[k][j], mn[k][j - 1]), std::swap(mx[k][j], mx[k][j - 1]);
+        }
     for (int k = 0; k < cnt; ++k)
         if (cid[k] >= (1 << 30)) cid[k] = collapse4(b, cid[k] - (1 << 30), o, depth + 1);
     for (int k = cnt; k < 4; ++k) {
