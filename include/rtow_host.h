@@ -62,6 +62,9 @@ uint32_t rth_translate(RthScene* s, uint32_t hitable, const float offset[3]);
 uint32_t rth_rotate_y(RthScene* s, uint32_t hitable, float angle_degrees);
 /* hitable.rs:529-533: turn the world entry `hitable` into ConstantMedium::new(hitable, density, phase_tex) */
 uint32_t rth_constant_medium(RthScene* s, uint32_t hitable, float density, uint32_t phase_tex);
+/* Hitable::bbox (hitable.rs:52) of a world entry, wrappers included: out = {min.xyz, max.xyz}; returns the trait
+ * method's bool (1/0), < 0 on a bad handle.  BvhNode::new sorts by it (hitable.rs:163-174). */
+int rth_hitable_bbox(RthScene* s, uint32_t hitable, float out[6]);
 /* sky = RtSkyType; env_path only for RT_SKY_ENV */
 int rth_set_sky(RthScene* s, uint32_t sky, const char* env_path);
 int rth_set_camera(RthScene* s, const float lookfrom[3], const float lookat[3], const float vup[3], float vfov,

@@ -72,6 +72,7 @@ def load():
     lib.orc_sphere_scene_layout.argtypes = [C.c_uint64, f]
     lib.orc_sphere_scene_layout.restype = C.c_uint32
     lib.orc_final_scene_layout.argtypes = [C.c_uint64, f, f]
+    lib.orc_entry_bbox.argtypes = [C.POINTER(RtFlatScene), C.c_uint32, f]
     lib.orc_bvh_stats.argtypes = [C.POINTER(RtFlatScene), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.orc_bvh_stats.restype = C.c_uint32
     _lib = lib

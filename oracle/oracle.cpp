@@ -1516,6 +1516,12 @@ static void final_scene_bvh_axes(Xoshiro256pp& r, size_t span) {
         final_scene_bvh_axes(r, span - span / 2);
     }
 }
+/* Hitable::bbox of world entry `idx` of a flat scene (sphere, rect or medium, through its wrapper chain):
+ * hitable.rs:104-108, 274-278, 420-431, 449-474, 581-583.  out = {min.xyz, max.xyz}. */
+void orc_entry_bbox(const RtFlatScene* fs, uint32_t idx, float out[6]) {
+    const AABB b = sphere_bbox(*fs, (int)idx);
+    out[0] = b.mn.x, out[1] = b.mn.y, out[2] = b.mn.z, out[3] = b.mx.x, out[4] = b.mx.y, out[5] = b.mx.z;
+}
 void orc_final_scene_layout(uint64_t seed, float* centres /* [3000] */, float* heights /* [400] */) {
     Xoshiro256pp rng = smallrng_seed_from_u64(seed);
     std::vector<float> vec(768);

@@ -100,7 +100,7 @@ GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_err
                "rt_get_depth_timings", "rt_set_progress"]
 HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
                 "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
-                "rth_sphere", "rth_rect", "rth_gbox", "rth_translate", "rth_rotate_y", "rth_constant_medium", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
+                "rth_sphere", "rth_rect", "rth_gbox", "rth_translate", "rth_rotate_y", "rth_constant_medium", "rth_hitable_bbox", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
                 "rth_scene_camera", "rth_scene_sphere_name", "rth_scene_free", "rth_png_write", "rth_output_file_name"]
 
 _gpu_lib = None
@@ -190,6 +190,8 @@ def load_host_library():
     lib.rth_rotate_y.restype = C.c_uint32
     lib.rth_constant_medium.argtypes = [vp, C.c_uint32, C.c_float, C.c_uint32]
     lib.rth_constant_medium.restype = C.c_uint32
+    lib.rth_hitable_bbox.argtypes = [vp, C.c_uint32, C.c_float * 6]
+    lib.rth_hitable_bbox.restype = C.c_int
     lib.rth_set_sky.argtypes = [vp, C.c_uint32, C.c_char_p]
     lib.rth_set_sky.restype = C.c_int
     lib.rth_set_camera.argtypes = [vp, f3, f3, f3, C.c_float, C.c_float]

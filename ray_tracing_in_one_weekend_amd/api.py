@@ -87,6 +87,14 @@ class Scene:
     def constant_medium(self, hitable, density, phase_tex):
         return self._check(self._lib.rth_constant_medium(self._h, hitable, C.c_float(density), phase_tex))
 
+    def bbox(self, hitable):
+        """Hitable::bbox of a world entry (hitable.rs:52): (has_box, [min.xyz, max.xyz])."""
+        out = (C.c_float * 6)()
+        rc = self._lib.rth_hitable_bbox(self._h, hitable, out)
+        if rc < 0:
+            raise RtError(self._lib.rth_last_error().decode())
+        return bool(rc), np.array(out, dtype=np.float32)
+
     def set_sky(self, sky, env_path=None):
         if self._lib.rth_set_sky(self._h, sky, env_path.encode() if env_path else None) != 0:
             raise RtError(self._lib.rth_last_error().decode())

@@ -203,6 +203,18 @@ uint32_t rth_translate(RthScene* s, uint32_t hitable, const float offset[3]) {
         return hitable;
     });
 }
+// Hitable::bbox of world entry `hitable` (hitable.rs:52): {min.xyz, max.xyz}.  Returns 1/0 like the trait method, < 0 on error.
+int rth_hitable_bbox(RthScene* s, uint32_t hitable, float out[6]) {
+    int has = 0;
+    const int rc = guarded([&] {
+        if (!out || hitable >= s->world.size()) throw std::runtime_error("rth_hitable_bbox: bad argument");
+        AABB b;
+        has = s->world[hitable]->bbox(b) ? 1 : 0;
+        out[0] = b.min.x, out[1] = b.min.y, out[2] = b.min.z, out[3] = b.max.x, out[4] = b.max.y, out[5] = b.max.z;
+        return RT_OK;
+    });
+    return rc != RT_OK ? -1 : has;
+}
 uint32_t rth_rotate_y(RthScene* s, uint32_t hitable, float angle_degrees) {
     return guarded_handle([&]() -> uint32_t {
         if (hitable >= s->world.size()) throw std::runtime_error("rth_rotate_y: bad hitable handle");

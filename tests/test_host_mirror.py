@@ -213,3 +213,43 @@ def test_png_writer_and_output_name(rt, tmp_path):
     t = 1715972624  # any fixed instant: the name is the local wall-clock time of it
     lt = time.localtime(t)
     assert rt.output_file_name(t) == time.strftime("%Y-%m-%dT%H-%M-%S.png", lt)
+
+
+def test_bbox_of_wrapped_hitables_matches_the_oracle(rt, orc):
+    """Two independent restatements of Hitable::bbox (the host mirror's virtual methods, the oracle's flat-scene
+    functions) through random Translate / RotateY chains: hitable.rs:104-108, 274-278, 420-431, 449-474, 581-583.
+    BvhNode::new sorts by these boxes, so they decide the tree shape the mirror reproduces."""
+    rng = np.random.default_rng(11)
+    s = rt.Scene.new()
+    m = s.material(rt._ffi.MAT_DIFFUSE, tex0=s.constant_tex((0.5, 0.5, 0.5)))
+    handles = []
+    for i in range(60):
+        if i % 2 == 0:
+            h = s.sphere(tuple(rng.uniform(-50, 50, 3)), float(rng.uniform(0.1, 9)), m, "s")
+        else:
+            mn = rng.uniform(-50, 40, 3)
+            h = s.rect(int(rng.integers(3)), tuple(mn), tuple(mn + rng.uniform(0.1, 20, 3)), m)
+        for _ in range(int(rng.integers(0, 4))):
+            h = s.translate(h, tuple(rng.uniform(-30, 30, 3))) if rng.random() < 0.5 else s.rotate_y(h, float(rng.uniform(-180, 180)))
+        if i % 7 == 0:
+            s.constant_medium(h, 0.5, s.constant_tex((1, 1, 1)))
+        handles.append(h)
+    boxes = [s.bbox(h) for h in handles]
+    s.set_camera((0, 0, 100), (0, 0, 0), (0, 1, 0), 40, 1.0)
+    s.finish(use_bvh=False)
+    fs = s.flat
+    lib = orc.load()
+    n_prims = fs.n_spheres + fs.n_rects
+    a = s.arrays()
+    # construction order: spheres are entries 0.., rects n_spheres..; a medium's box is its boundary's (hitable.rs:581-583)
+    si = ri = 0
+    for i, (has, box) in enumerate(boxes):
+        idx = si if i % 2 == 0 else fs.n_spheres + ri
+        si, ri = si + (i % 2 == 0), ri + (i % 2 == 1)
+        want = np.zeros(6, np.float32)
+        lib.orc_entry_bbox(s.flat_ptr, idx, orc._fp(want))
+        assert has and np.array_equal(box.view(np.uint32), want.view(np.uint32)), (i, box, want)
+        med = (a["sph_medium"][idx] if idx < fs.n_spheres else a["rect_medium"][idx - fs.n_spheres])
+        if med != rt._ffi.NO_XFORM:
+            lib.orc_entry_bbox(s.flat_ptr, n_prims + int(med), orc._fp(want))
+            assert np.array_equal(box.view(np.uint32), want.view(np.uint32))
