@@ -60,6 +60,7 @@ struct Builder {
     std::vector<uint32_t> order;
     HostBvh& out;
     bool median_only;
+    size_t sweep_max = 4096; // ranges up to this size use the exact sweep SAH
 
     // `prim` = tight primitive bounds (sphere: c -+ r; rectangle: its plane slab)
     Builder(const std::vector<PrimBox>& prim, HostBvh& o, bool median) : out(o), median_only(median) {
@@ -106,7 +107,38 @@ struct Builder {
         auto cen = [&](uint32_t id) { return this->cen[3 * (size_t)id + (size_t)axis]; };
         size_t mid = first + count / 2;
         bool done = false;
-        if (!median_only && ext > 0.0f && count > 2) {
+        // Small ranges: exact sweep SAH over all three axes (every split position between centroid-sorted
+        // primitives) instead of 16 bins on the widest axis; the binned search takes over above RT_SWEEP_MAX.
+        if (!median_only && count > 2 && count <= sweep_max) {
+            float best = FLT_MAX;
+            int best_axis = -1;
+            size_t best_mid = 0;
+            std::vector<uint32_t> tmp(order.begin() + (long)first, order.begin() + (long)(first + count));
+            std::vector<float> right(count);
+            for (int ax = 0; ax < 3; ++ax) {
+                std::stable_sort(tmp.begin(), tmp.end(), [&](uint32_t x, uint32_t y) { return this->cen[3 * (size_t)x + (size_t)ax] < this->cen[3 * (size_t)y + (size_t)ax]; });
+                Box acc;
+                acc.reset();
+                for (size_t i = count; i-- > 1;) {
+                    acc.grow(boxes[tmp[i]]);
+                    right[i] = acc.half_area();
+                }
+                acc.reset();
+                for (size_t i = 1; i < count; ++i) {
+                    acc.grow(boxes[tmp[i - 1]]);
+                    const float cost = acc.half_area() * (float)i + right[i] * (float)(count - i);
+                    if (cost < best) best = cost, best_axis = ax, best_mid = i;
+                }
+            }
+            if (best_axis >= 0) {
+                std::stable_sort(order.begin() + (long)first, order.begin() + (long)(first + count), [&](uint32_t x, uint32_t y) {
+                    return this->cen[3 * (size_t)x + (size_t)best_axis] < this->cen[3 * (size_t)y + (size_t)best_axis];
+                });
+                mid = first + best_mid;
+                done = true;
+            }
+        }
+        if (!done && !median_only && ext > 0.0f && count > 2) {
             const int NB = 16;
             Box bb[NB];
             size_t bn[NB] = {0};
