@@ -241,23 +241,40 @@ inline int collapse4(const HostBvh& b, int n, HostBvh4& o, uint32_t depth) {
         lmn[0] = A.x, lmn[1] = A.y, lmn[2] = A.z, lmx[0] = A.w, lmx[1] = B.x, lmx[2] = B.y;
         rmn[0] = B.z, rmn[1] = B.w, rmn[2] = C.x, rmx[0] = C.y, rmx[1] = C.z, rmx[2] = C.w;
     };
-    float lmn[3], lmx[3], rmn[3], rmx[3];
-    boxes(n, lmn, lmx, rmn, rmx);
-    const int ch[2] = {b.d[(size_t)n].x, b.d[(size_t)n].y};
-    const float* cmn[2] = {lmn, rmn};
-    const float* cmx[2] = {lmx, rmx};
-    // inner grandchildren are marked with (1 << 30) + node and resolved after this node is filled
-    for (int k = 0; k < 2; ++k) {
-        if (ch[k] == INT_MIN) continue;
-        if (ch[k] >= 0) {
-            float gl[3], glx[3], gr[3], grx[3];
-            boxes(ch[k], gl, glx, gr, grx);
-            const int g[2] = {b.d[(size_t)ch[k]].x, b.d[(size_t)ch[k]].y};
-            if (g[0] != INT_MIN) add(gl, glx, g[0] >= 0 ? (1 << 30) + g[0] : g[0]);
-            if (g[1] != INT_MIN) add(gr, grx, g[1] >= 0 ? (1 << 30) + g[1] : g[1]);
-        } else {
-            add(cmn[k], cmx[k], ch[k]);
+    // Greedy collapse: start from the two children of `n`; while there is room, replace the inner child with the
+    // largest box by its own two children.  Compared with always taking the four grandchildren this fills the
+    // nodes of unbalanced subtrees (a leaf next to a deep sibling) and opens the box a ray is most likely to enter.
+    {
+        float lmn[3], lmx[3], rmn[3], rmx[3];
+        boxes(n, lmn, lmx, rmn, rmx);
+        const int ch[2] = {b.d[(size_t)n].x, b.d[(size_t)n].y};
+        if (ch[0] != INT_MIN) add(lmn, lmx, ch[0] >= 0 ? (1 << 30) + ch[0] : ch[0]);
+        if (ch[1] != INT_MIN) add(rmn, rmx, ch[1] >= 0 ? (1 << 30) + ch[1] : ch[1]);
+    }
+    for (;;) {
+        int pick = -1;
+        float pick_area = -1.0f;
+        for (int k = 0; k < cnt; ++k) {
+            if (cid[k] < (1 << 30)) continue; // a leaf
+            const float e0 = mx[0][k] - mn[0][k], e1 = mx[1][k] - mn[1][k], e2 = mx[2][k] - mn[2][k];
+            const float area = e0 * e1 + e1 * e2 + e2 * e0;
+            if (area > pick_area) pick_area = area, pick = k;
         }
+        if (pick < 0) break;
+        const int node = cid[pick] - (1 << 30);
+        const int g[2] = {b.d[(size_t)node].x, b.d[(size_t)node].y};
+        const int n_new = (g[0] != INT_MIN) + (g[1] != INT_MIN);
+        if (cnt - 1 + n_new > 4) break;
+        float gl[3], glx[3], gr[3], grx[3];
+        boxes(node, gl, glx, gr, grx);
+        // remove `pick`, append its children
+        for (int k = pick; k + 1 < cnt; ++k) {
+            cid[k] = cid[k + 1];
+            for (int ax = 0; ax < 3; ++ax) mn[ax][k] = mn[ax][k + 1], mx[ax][k] = mx[ax][k + 1];
+        }
+        --cnt;
+        if (g[0] != INT_MIN) add(gl, glx, g[0] >= 0 ? (1 << 30) + g[0] : g[0]);
+        if (g[1] != INT_MIN) add(gr, grx, g[1] >= 0 ? (1 << 30) + g[1] : g[1]);
     }
     // leaves first: sphere-only scenes test a leaf child inside the node step (rt_kernels.h), and a hit there
     // tightens the limit the inner children that follow are culled against
