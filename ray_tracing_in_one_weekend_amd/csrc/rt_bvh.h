@@ -2,11 +2,12 @@
 //
 // The reference accelerates closest-hit with a random-axis median-split BVH of trait objects
 // (hitable.rs:158-241).  The GPU path keeps the RESULT of HitableList::hit (hitable.rs:117-132:
-// the closest root, ties to the later sphere) but searches with its own structure: a binned-SAH
-// BVH2 whose nodes hold both child boxes (one LDS fetch per visit decides both children),
-// single-primitive leaves, boxes padded so that culling is conservative with respect to the exact
-// Sphere::hit / XYRect::hit arithmetic.  Culling never changes which sphere wins, so results are identical to
-// the brute-force list walk (tests/test_gpu_parity.py::test_bvh_equals_brute_force).
+// the closest root, ties to the later object) but searches with its own structure: a SAH BVH2 over the
+// world entries (exact sweep over three axes for ranges up to 4096, 16 bins above), single-entry
+// leaves, boxes padded so that culling is conservative with respect to the exact Sphere::hit /
+// XYRect::hit arithmetic, collapsed greedily into 4-wide nodes (collapse_bvh4) that one set of
+// 7 LDS reads decides.  Culling never changes which entry wins, so results are identical to the
+// brute-force list walk (tests/test_gpu_parity.py::test_bvh_equals_brute_force_on_adversarial_rays).
 #pragma once
 #include <hip/hip_runtime.h>
 
