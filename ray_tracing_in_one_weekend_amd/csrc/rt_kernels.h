@@ -507,10 +507,11 @@ __device__ __forceinline__ void leaf_test(const BvhLds& L, int s, V3 o, V3 d, fl
 // sphere replaces an earlier one), independent of the visiting order.  Boxes are padded at build time
 // (rt_bvh.h) so that a box is never culled when the exact test could accept the sphere inside it.
 //
-// Sphere-only scenes test a leaf child as soon as its box is hit instead of pushing it: one loop trip (pop, branch,
-// re-converge) less per leaf and a tighter tbest for the children that follow; k_intersect -4.7 % on config 2.  In
-// general scenes the same change helps cornell_box (+6 %) and hurts final_scene and simple_light_scene (-10 %,
-// -24 %: their leaves are 2-3x the code, inlined four times), so they keep the stack.
+// Sphere-only scenes test the leaf children of a node inside its node step instead of pushing them: the hit leaves
+// are queued in two registers during the four box tests and tested in one loop behind them (one loop trip of the
+// outer traversal less per leaf; k_intersect -6.5 % on config 2).  In general scenes testing leaves in the node step
+// helps cornell_box (+6 %) and hurts final_scene and simple_light_scene (-10 %, -24 %: their leaf code is 2-3x
+// larger), so they keep the stack.
 //
 // Slab arithmetic: t = b*inv - o*inv as one fused multiply-add per plane (the only place in the
 // library that fuses; it is a culling test, not reference arithmetic; 4 % faster than (b-o)*inv.
@@ -530,7 +531,8 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
         const float4 mnx = L.pl[0][cur], mny = L.pl[1][cur], mnz = L.pl[2][cur];
         const float4 mxx = L.pl[3][cur], mxy = L.pl[4][cur], mxz = L.pl[5][cur];
         const int4 id = L.id[cur];
-        float tb = __builtin_fmaf(tbest, 1.000004f, eps);
+        const float tb = __builtin_fmaf(tbest, 1.000004f, eps);
+        uint32_t lq0 = 0u, lq1 = 0u; // sphere-only: the hit leaf children of this node, id + 1 in 16 bits each
         float best_t = RT_FLT_MAX;
         int best = (int)0x80000000;
 #define RT_CHILD(K, IDK)                                                                                      \
@@ -541,9 +543,9 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
         const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));              \
         const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));                           \
         if (tn <= fminf(__builtin_fmaf(tf, 1.000004f, eps), tb) && IDK != (int)0x80000000) {                  \
-            if (!RECTS && IDK < 0) { /* a sphere leaf: tested now instead of pushed and popped (see below) */      \
-                leaf_test<RECTS>(L, ~IDK, o, d, a, pend, tbest, hit);                                          \
-                tb = __builtin_fmaf(tbest, 1.000004f, eps);                                                    \
+            if (!RECTS && IDK < 0) { /* a sphere leaf: queued for the leaf loop behind the four box tests */     \
+                lq1 = (lq1 << 16) | (lq0 >> 16);                                                               \
+                lq0 = (lq0 << 16) | (uint32_t)(~IDK + 1);                                                      \
             } else if (tn < best_t) { /* new nearest: the previous nearest (if any) goes on the stack */      \
                 if (best != (int)0x80000000) {                                                                \
                     L.stack[sp * BLOCK] = (unsigned short)best;                                               \
@@ -573,6 +575,16 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
 #undef RT_T
         }
 #undef RT_CHILD
+        // the leaves of the node in one loop: every trip tests one sphere per lane that still has one, instead of
+        // four inlined tests that each run for the few lanes whose child k happens to be a hit leaf
+        if (!RECTS) {
+            while (lq0 != 0u) {
+                const int s = (int)(lq0 & 0xFFFFu) - 1;
+                lq0 = (lq0 >> 16) | (lq1 << 16);
+                lq1 >>= 16;
+                leaf_test<RECTS>(L, s, o, d, a, pend, tbest, hit);
+            }
+        }
         if (best != (int)0x80000000) {
             cur = best;
             return false;
