@@ -496,22 +496,23 @@ __device__ __forceinline__ void leaf_test(const BvhLds& L, int s, V3 o, V3 d, fl
     }
 }
 
-// One traversal step of one lane.  `cur` >= 0: inner node — slab-test the 4 child boxes against
-// [0, tbest], continue with the nearest hit child, push the other hit children (unsorted: the visit
-// count is the same as with a full sort, 7.32 vs 7.29 node visits per ray on sphere_scene; a binary
-// tree needs 13.2 and measured 6 % slower).  `cur` < 0: sphere ~cur — exact Sphere::hit roots
-// (hitable.rs:75-91).  Returns true when the traversal of this ray has finished.
+// One traversal step of one lane.  `cur` is an inner node: slab-test the 4 child boxes against [0, tbest], run the
+// exact test of the hit leaf children (spheres: Sphere::hit roots, hitable.rs:75-91), continue with the nearest hit
+// inner child and push the other hit inner children (unsorted: the visit count is the same as with a full sort,
+// 7.32 vs 7.29 node visits per ray on sphere_scene; a binary tree needs 13.2 and measured 6 % slower).
+// Returns true when the traversal of this ray has finished.
 //
 // The winner is the smallest accepted root with ties to the larger sphere index, i.e. exactly what
 // the list walk of hitable.rs:117-132 returns (`t_max < root` rejects, so an equal root of a later
 // sphere replaces an earlier one), independent of the visiting order.  Boxes are padded at build time
 // (rt_bvh.h) so that a box is never culled when the exact test could accept the sphere inside it.
 //
-// Sphere-only scenes test the leaf children of a node inside its node step instead of pushing them: the hit leaves
-// are queued in two registers during the four box tests and tested in one loop behind them (one loop trip of the
-// outer traversal less per leaf; k_intersect -6.5 % on config 2).  In general scenes testing leaves in the node step
-// helps cornell_box (+6 %) and hurts final_scene and simple_light_scene (-10 %, -24 %: their leaf code is 2-3x
-// larger), so they keep the stack.
+// The leaf children of a node are tested inside its node step instead of being pushed: the hit leaves are queued in
+// two registers during the four box tests and tested in one loop behind them — one trip of the outer traversal
+// loop (pop, branch, re-converge) less per leaf, one instance of the leaf code, and every trip of the leaf loop
+// works for all lanes that still have a leaf.  k_intersect: config 2 -8 %, cornell_box -13 %, simple_light_scene
+// -5 %, final_scene unchanged.  (Four inlined tests, one per child slot, were 2 % slower on spheres and 10-24 %
+// slower on the larger leaf code of general scenes.)
 //
 // Slab arithmetic: t = b*inv - o*inv as one fused multiply-add per plane (the only place in the
 // library that fuses; it is a culling test, not reference arithmetic; 4 % faster than (b-o)*inv.
@@ -527,12 +528,12 @@ template <int BLOCK, bool RECTS>
 __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float nox, float noy,
                                          float noz, float eps, bool exact, float a, uint32_t& pend, int& cur, int& sp,
                                          float& tbest, int& hit) {
-    if (!RECTS || cur >= 0) { // sphere-only: leaves never reach the stack (tested inline below), cur is always a node
+    { // leaves never reach the stack (they are tested inside the node step below): cur is always a node
         const float4 mnx = L.pl[0][cur], mny = L.pl[1][cur], mnz = L.pl[2][cur];
         const float4 mxx = L.pl[3][cur], mxy = L.pl[4][cur], mxz = L.pl[5][cur];
         const int4 id = L.id[cur];
         const float tb = __builtin_fmaf(tbest, 1.000004f, eps);
-        uint32_t lq0 = 0u, lq1 = 0u; // sphere-only: the hit leaf children of this node, id + 1 in 16 bits each
+        uint32_t lq0 = 0u, lq1 = 0u; // the hit leaf children of this node, entry id + 1 in 16 bits each
         float best_t = RT_FLT_MAX;
         int best = (int)0x80000000;
 #define RT_CHILD(K, IDK)                                                                                      \
@@ -543,7 +544,7 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
         const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));              \
         const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));                           \
         if (tn <= fminf(__builtin_fmaf(tf, 1.000004f, eps), tb) && IDK != (int)0x80000000) {                  \
-            if (!RECTS && IDK < 0) { /* a sphere leaf: queued for the leaf loop behind the four box tests */     \
+            if (IDK < 0) { /* a leaf: queued for the leaf loop behind the four box tests */                   \
                 lq1 = (lq1 << 16) | (lq0 >> 16);                                                               \
                 lq0 = (lq0 << 16) | (uint32_t)(~IDK + 1);                                                      \
             } else if (tn < best_t) { /* new nearest: the previous nearest (if any) goes on the stack */      \
@@ -577,20 +578,16 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
 #undef RT_CHILD
         // the leaves of the node in one loop: every trip tests one sphere per lane that still has one, instead of
         // four inlined tests that each run for the few lanes whose child k happens to be a hit leaf
-        if (!RECTS) {
-            while (lq0 != 0u) {
-                const int s = (int)(lq0 & 0xFFFFu) - 1;
-                lq0 = (lq0 >> 16) | (lq1 << 16);
-                lq1 >>= 16;
-                leaf_test<RECTS>(L, s, o, d, a, pend, tbest, hit);
-            }
+        while (lq0 != 0u) {
+            const int s = (int)(lq0 & 0xFFFFu) - 1;
+            lq0 = (lq0 >> 16) | (lq1 << 16);
+            lq1 >>= 16;
+            leaf_test<RECTS>(L, s, o, d, a, pend, tbest, hit);
         }
         if (best != (int)0x80000000) {
             cur = best;
             return false;
         }
-    } else {
-        leaf_test<RECTS>(L, ~cur, o, d, a, pend, tbest, hit);
     }
     if (sp == 0) return true;
     --sp;
