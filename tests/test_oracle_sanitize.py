@@ -36,3 +36,21 @@ def test_oracle_runs_clean_under_asan_ubsan(built):
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, lib)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sanitized ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_host_mirror_runs_clean_under_asan_ubsan(tmp_path):
+    """The C++ mirror of the reference's constructors (host/rtow.hpp, demo_scene.cpp, host_capi.cpp, png_out.cpp) built
+    with AddressSanitizer + UBSan: all seven scenes, the piecewise API with wrappers and media, bbox, PNG, file name."""
+    host = os.path.join(ROOT, "ray_tracing_in_one_weekend_amd", "host")
+    exe = str(tmp_path / "host_san")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off",
+           "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "host_sanitize_main.cpp")] + \
+          [os.path.join(host, f) for f in ("demo_scene.cpp", "host_capi.cpp", "png_out.cpp")] + ["-lz"]
+    c = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if c.returncode != 0 and "sanitize" in c.stderr:
+        pytest.skip("sanitizer runtime not available")
+    assert c.returncode == 0, c.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "final_scene rc=0 spheres=1007 rects=2401 media=1" in r.stdout and "finish rc=0" in r.stdout and "png rc=0" in r.stdout
