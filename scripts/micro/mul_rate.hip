@@ -1,4 +1,5 @@
-// Microbenchmark: issue rate of v_mul_lo_u32 against v_add_u32 / v_fma_f32 / v_mul_u32_u24 on gfx950.
+// Microbenchmark: issue rate of v_mul_lo_u32 against v_add_u32 / v_fma_f32 / v_mul_u32_u24, and of the transcendental
+// v_rcp_f32 / v_sqrt_f32 (each paired with one full-rate add), on gfx950.
 // hipcc --offload-arch=gfx950 -O3 -o mul_rate scripts/micro/mul_rate.hip && ./mul_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -12,6 +13,8 @@ __global__ void k(uint32_t* out, uint32_t seed, int iters) {
             if (OP == 0) { a = a * b; b = b * c; c = c * d; d = d * a; } // variable operands: no constant folding
             if (OP == 1) { a = a + 0x85EBCA6Bu ^ b; b = b + 0xC2B2AE35u ^ c; c = c + 0x9E3779B9u ^ d; d = d + 0x85EBCA6Bu ^ a; }
             if (OP == 2) { fa = fa * fb + fc; fb = fb * fc + fd; fc = fc * fd + fa; fd = fd * fa + fb; }
+            if (OP == 4) { fa = __builtin_amdgcn_rcpf(fa) + fb; fb = __builtin_amdgcn_rcpf(fb) + fc; fc = __builtin_amdgcn_rcpf(fc) + fd; fd = __builtin_amdgcn_rcpf(fd) + fa; } // rcp + add
+            if (OP == 5) { fa = __builtin_amdgcn_sqrtf(fa) + fb; fb = __builtin_amdgcn_sqrtf(fb) + fc; fc = __builtin_amdgcn_sqrtf(fc) + fd; fd = __builtin_amdgcn_sqrtf(fd) + fa; } // sqrt + add
             if (OP == 3) { a = __umul24(a, b) + c; b = __umul24(b, c) + d; c = __umul24(c, d) + a; d = __umul24(d, a) + b; }
         }
     }
@@ -35,8 +38,8 @@ int main() {
     (void)hipMalloc(&d, 256 * 32 * 256 * 4);
     const int iters = 2000;
     const double ops = 256.0 * 32 * 256 * iters * 16 * 4;
-    const char* names[4] = {"v_mul_lo_u32", "v_add+xor (2 ops)", "v_fma_f32", "v_mad_u32_u24"};
-    float ms[4] = {run<0>(d, iters), run<1>(d, iters), run<2>(d, iters), run<3>(d, iters)};
-    for (int i = 0; i < 4; ++i) printf("%-20s %8.3f ms  %8.2f Tops/s (lane-ops)\n", names[i], ms[i], ops / ms[i] / 1e9);
+    const char* names[6] = {"v_mul_lo_u32", "v_add+xor (2 ops)", "v_fma_f32", "v_mad_u32_u24", "v_rcp_f32 + v_add", "v_sqrt_f32 + v_add"};
+    float ms[6] = {run<0>(d, iters), run<1>(d, iters), run<2>(d, iters), run<3>(d, iters), run<4>(d, iters), run<5>(d, iters)};
+    for (int i = 0; i < 6; ++i) printf("%-20s %8.3f ms  %8.2f Tops/s (lane-ops)\n", names[i], ms[i], ops / ms[i] / 1e9);
     return 0;
 }
