@@ -264,6 +264,28 @@ __device__ __forceinline__ bool prim_root(const Tables& sc, const float4* geo, u
     const uint32_t gi = sc.n_spheres + 2u * (s - sc.n_spheres);
     return rect_root(geo[gi], geo[gi + 1u], o, d, t_min, t_max, th);
 }
+// The object-space ray of the wrapper chain used last: the leaves of one node usually share their chain (the
+// instanced spheres of a cloud), so the leaf loop of a node step moves the ray once instead of once per leaf.
+struct ChainCache {
+    uint32_t xf; // RT_NO_XFORM_DEV = empty
+    V3 o, d;
+};
+template <class Tables>
+__device__ __forceinline__ bool prim_root_cached(const Tables& sc, const float4* geo, uint32_t s, V3 o, V3 d, float t_min,
+                                                 float t_max, ChainCache& cc, float& th) {
+    const uint32_t xf = sc.prim_xform[s];
+    if (xf != RT_NO_XFORM_DEV) {
+        if (xf != cc.xf) {
+            cc.o = o, cc.d = d;
+            chain_to_object(sc, load_chain(sc, xf), cc.o, cc.d);
+            cc.xf = xf;
+        }
+        o = cc.o, d = cc.d;
+    }
+    if (s < sc.n_spheres) return sphere_root(geo[s], o, d, length_squared(d), t_min, t_max, th);
+    const uint32_t gi = sc.n_spheres + 2u * (s - sc.n_spheres);
+    return rect_root(geo[gi], geo[gi + 1u], o, d, t_min, t_max, th);
+}
 // Root of one boundary primitive for a ray that is already in the object space of the medium's common chain
 // (RAW) or still in world space (the primitive applies its own chain).
 template <bool RAW, class Tables>
@@ -471,7 +493,7 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
 // accept.  Sphere-only scenes: Sphere::hit roots (hitable.rs:75-91).
 template <bool RECTS>
 __device__ __forceinline__ void leaf_test(const BvhLds& L, int s, V3 o, V3 d, float a, uint32_t& pend, float& tbest,
-                                          int& hit) {
+                                          int& hit, ChainCache* cc = nullptr) {
     float th;
     // candidate root of this primitive (independent of tbest), then the order-independent accept
     bool ok;
@@ -487,7 +509,8 @@ __device__ __forceinline__ void leaf_test(const BvhLds& L, int s, V3 o, V3 d, fl
             pend |= 1u << ((uint32_t)s - L.gt.n_prims);
             ok = false;
         } else {
-            ok = prim_root(L.gt, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
+            ok = cc ? prim_root_cached(L.gt, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, *cc, th)
+                    : prim_root(L.gt, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
         }
     }
     if (ok && (th < tbest || (th == tbest && s > hit))) {
@@ -578,11 +601,13 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
 #undef RT_CHILD
         // the leaves of the node in one loop: every trip tests one sphere per lane that still has one, instead of
         // four inlined tests that each run for the few lanes whose child k happens to be a hit leaf
+        ChainCache cc;
+        cc.xf = RT_NO_XFORM_DEV;
         while (lq0 != 0u) {
             const int s = (int)(lq0 & 0xFFFFu) - 1;
             lq0 = (lq0 >> 16) | (lq1 << 16);
             lq1 >>= 16;
-            leaf_test<RECTS>(L, s, o, d, a, pend, tbest, hit);
+            leaf_test<RECTS>(L, s, o, d, a, pend, tbest, hit, RECTS ? &cc : nullptr);
         }
         if (best != (int)0x80000000) {
             cur = best;
