@@ -41,7 +41,9 @@ step moves {b['roofline']['achieved'] / 1e3:.2f} TB/s of algorithmic bytes ({b['
 the VALU issue slots are the bound (`profiles/round1/valu_config2.json`, `scripts/collect_valu.py`:
 `SQ_INSTS_VALU` against 1024 SIMDs × 2.4 GHz / 4 cycles per wave64 instruction): `k_intersect` saturated
 ({vi['issue_frac']:.2f} of the model's peak) with {100 * vi['lane_util']:.0f} % of the lanes active per instruction, `k_shade` {vs['issue_frac']:.2f} with {100 * vs['lane_util']:.0f} %; `bench.py`
-carries these as `roofline.valu`.  """
+carries these as `roofline.valu`.
+
+"""
 p = os.path.join(root, "DESIGN.md")
 s = open(p).read()
 a0, a1 = s.index("rocprofv3 (`profiles/round1/r1_final_kernel_stats.csv`"), s.index("What was tried and measured no better")
