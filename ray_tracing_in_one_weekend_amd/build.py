@@ -7,7 +7,10 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+# -fno-slp-vectorize: the SLP vectoriser pairs the x/y/z arithmetic of the V3 helpers into v_pk_mul_f32 / v_pk_add_f32,
+# which issue at half the rate of the scalar forms on gfx950 (same lane-ops per cycle, profiles/round2/valu_peak.json)
+# but need aligned register pairs and v_pk_mov shuffles: k_shade 6 % and k_intersect 1 % faster without (same bits).
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared",
                "-Wall", "-Wno-unused-function"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra"]
 

@@ -118,9 +118,13 @@ bool mat_needs_tex0(uint32_t t) {
            t == RT_MAT_DISNEY_DIFFUSE || t == RT_MAT_DISNEY_METAL || t == RT_MAT_DISNEY_SHEEN;
 }
 
-struct SliceTiming {
-    hipEvent_t t0, t1;
-};
+// The cheap shading classes (1 + material*4 + texture of tex0; 0 = miss): no hit under the gradient / black sky, and
+// the material.rs materials over a ConstantTex (Metal and Dielectric have no texture).
+bool class_is_light(uint32_t cls, uint32_t sky_type) {
+    if (cls == 0) return sky_type != RT_SKY_ENV;
+    const uint32_t ty = (cls - 1u) / 4u, tt = (cls - 1u) % 4u;
+    return tt == RT_TEX_CONSTANT && ty <= RT_MAT_ISOTROPIC;
+}
 
 } // namespace
 
@@ -163,6 +167,27 @@ int rt_ctx_create(int device_id, RtCtx** out_ctx) {
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->lds_limit = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 64 * 1024; // 160 KiB on gfx950
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    // Kernels whose dynamic LDS can exceed the 64 KB default: the attribute is process-global per function, so it is
+    // set to the device limit once (a per-scene value would be lowered by the next context's smaller scene).
+    {
+        const void* variants[] = {
+#define RT_ISECT_VARIANTS(G, R, N, T) reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, G, R, N, T>)
+            RT_ISECT_VARIANTS(false, false, true, false), RT_ISECT_VARIANTS(false, true, true, false),
+            RT_ISECT_VARIANTS(true, false, true, false),  RT_ISECT_VARIANTS(true, true, true, false),
+            RT_ISECT_VARIANTS(false, true, false, false), RT_ISECT_VARIANTS(true, true, false, false),
+            RT_ISECT_VARIANTS(false, true, true, true),   RT_ISECT_VARIANTS(true, true, true, true),
+            RT_ISECT_VARIANTS(false, true, false, true),  RT_ISECT_VARIANTS(true, true, false, true),
+#undef RT_ISECT_VARIANTS
+            reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, true>),
+            reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, false>),
+#define RT_SHADE_VARIANTS(P, G) reinterpret_cast<const void*>(&k_shade<P, G, false>), reinterpret_cast<const void*>(&k_shade<P, G, true>)
+            RT_SHADE_VARIANTS(true, true), RT_SHADE_VARIANTS(true, false), RT_SHADE_VARIANTS(false, true), RT_SHADE_VARIANTS(false, false),
+#undef RT_SHADE_VARIANTS
+        };
+        for (const void* fn : variants)
+            if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_limit)) != hipSuccess)
+                return bail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
+    }
     if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail("hipEventCreate", e);
     *out_ctx = ctx;
@@ -327,6 +352,9 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     for (size_t k = 0; k < pvec.size(); ++k)
         pvec[k] = make_float4(s->perlin_vec[3 * k], s->perlin_vec[3 * k + 1], s->perlin_vec[3 * k + 2], 0.0f);
     for (size_t k = 0; k < pperm.size(); ++k) pperm[k] = (uint8_t)s->perlin_perm[k];
+    std::vector<unsigned short> pperm2(pperm.size()); // entry i with its successor on the 256-ring (PerlinTables)
+    for (size_t k = 0; k < pperm.size(); ++k)
+        pperm2[k] = (unsigned short)(pperm[k] | (pperm[(k & ~(size_t)255) + ((k + 1) & 255)] << 8));
     std::vector<ImgRec> imgs(s->n_images);
     std::vector<float4> texels((size_t)n_texels);
     for (uint32_t k = 0; k < s->n_images; ++k) {
@@ -475,6 +503,8 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     }
     std::vector<uint8_t> sclass(n_entries);
     std::vector<float4> srec((size_t)n_entries * 5);
+    bool class_present[RT_NCLASS] = {};
+    class_present[0] = true; // "miss"
     for (uint32_t i = 0; i < n_entries; ++i) {
         const bool is_med = i >= n_prims;
         const bool is_rect = !is_med && i >= s->n_spheres;
@@ -484,6 +514,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         const uint32_t t0 = has_t0 ? s->mat_tex0[m] : 0u;
         const uint32_t tt = has_t0 ? s->tex_type[t0] : 0u;
         sclass[i] = (uint8_t)(1u + ty * 4u + tt); // < RT_NCLASS
+        class_present[sclass[i]] = true;
         // colour slot: the texture's colour 0 for textured materials, the albedo for Metal
         const float* col = has_t0 ? s->tex_color0 + 3 * (size_t)t0 : s->mat_color + 3 * (size_t)m;
         srec[5 * (size_t)i + 0] = is_med ? make_float4(0.f, 0.f, 0.f, 1.f) : (is_rect ? rgeo[2 * (size_t)(i - s->n_spheres)] : geo[i]);
@@ -492,6 +523,15 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         srec[5 * (size_t)i + 3] = make_float4(s->mat_p1[m], s->mat_p2[m], has_t0 ? s->tex_scale[t0] : 0.0f, fbits(s->mat_tex0[m]));
         srec[5 * (size_t)i + 4] = is_rect ? rgeo[2 * (size_t)(i - s->n_spheres) + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+
+    // sort keys of k_shade's class sort: the classes present in the scene ranked cheap classes first (a miss and the
+    // constant-texture material.rs materials, then the textured and pbr.rs ones), so that the long Perlin / PBR
+    // segments of a block sit together at its end
+    uint32_t class_key[RT_NCLASS] = {}, n_keys = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (uint32_t c = 0; c < RT_NCLASS; ++c)
+            if (class_present[c] && class_is_light(c, s->sky_type) == (pass == 0)) class_key[c] = n_keys++;
+    for (uint32_t i = 0; i < n_entries; ++i) sclass[i] = (uint8_t)class_key[sclass[i]];
 
     HostBvh4 bvh4;
     collapse_bvh4(bvh, bvh4);
@@ -516,6 +556,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         ds.bvh_exact_eps = (float)(std::sqrt(ext2) / 1024.0);
     }
     ds.bvh4_depth = bvh4.depth;
+    ds.key_miss = class_key[0];
     ds.n_spheres = s->n_spheres, ds.n_materials = s->n_materials, ds.n_textures = s->n_textures;
     ds.n_perlin = s->n_perlin, ds.n_images = s->n_images, ds.sky_type = s->sky_type, ds.sky_image = s->sky_image;
     int rc;
@@ -523,7 +564,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     pgeo.insert(pgeo.end(), rgeo.begin(), rgeo.end());
     if ((rc = upload(ctx, pgeo, &ds.prim_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
-        (rc = upload(ctx, pperm, &ds.perlin_perm)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
+        (rc = upload(ctx, pperm2, &ds.perlin_perm2)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
         (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, pmed, &ds.prim_medium)) || (rc = upload(ctx, med_prims, &ds.med_prims)) || (rc = upload(ctx, med_range, &ds.med_range)) || (rc = upload(ctx, med_xf, &ds.med_xform)) ||
         (rc = upload(ctx, ent_bs, &ds.ent_bs)) || (rc = upload(ctx, entry_ids, &ds.ent_leaf)) ||
         (rc = upload(ctx, med_nid, &ds.med_neg_inv_density)) || (rc = upload(ctx, pxf, &ds.prim_xform)) || (rc = upload(ctx, xparam, &ds.xf_param)) ||
@@ -553,23 +594,6 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         !getenv("RTOW_NO_GENERAL_LDS")) {
         ctx->isect_lds += general_lds_bytes(ds);
         ctx->general_lds = true;
-    }
-    if (ctx->use_bvh) {
-        const void* variants[] = {
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, false, true, false>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, true, false>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, false, true, false>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, true, false>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, false, false>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, false, false>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, true, true>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, true, true>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, false, true, false, true>),
-            reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, true, true, false, true>),
-            reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, true>),
-            reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, false>)};
-        for (const void* fn : variants)
-            RT_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->isect_lds));
     }
     return RT_OK;
 }
@@ -605,7 +629,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t npix = (uint32_t)npix64;
     // slice size: few, large slices amortise the short-queue tail of the bounce loop (depths > ~12 hold a few
     // thousand rays) — config 2 measured 99 / 88 / 82 / 79.5 ms per frame with 8 / 4 / 2 / 1 slices.  A ray of
-    // the slice costs 116 B of work buffers (two 48 B queues, 8 B hit record, 12 B radiance slot): up to 640 Mi
+    // the slice costs 120 B of work buffers (two 48 B queues, 8 B hit record, 16 B radiance slot): up to 640 Mi
     // rays (74 GiB of the 288 GB HBM), less when the device has less memory to give.
     uint32_t S = prm->spp_slice;
     if (S == 0) {
@@ -614,7 +638,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             size_t held = ctx->rad.bytes + ctx->qhit.bytes;
             for (const DevBuf& b : ctx->qbuf) held += b.bytes;
-            max_rays = std::min<uint64_t>(max_rays, (uint64_t)((double)(free_b + held) * 0.5 / 116.0));
+            max_rays = std::min<uint64_t>(max_rays, (uint64_t)((double)(free_b + held) * 0.5 / 120.0));
         }
         S = (uint32_t)std::max<uint64_t>(1, max_rays / npix64);
     }
@@ -645,7 +669,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     for (auto& b : ctx->qbuf)
         if ((rc = ensure(ctx, b, qbytes))) return rc;
     if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
-    if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * 3 * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * sizeof(float4)))) return rc;
     if ((rc = ensure(ctx, ctx->acc, (size_t)npix * 3 * sizeof(float)))) return rc;
     const size_t counts_bytes = (size_t)(n_depths + 1) * nq * sizeof(uint32_t); // queue sizes [depth][shard]
     if ((rc = ensure(ctx, ctx->counts, counts_bytes))) return rc;
@@ -662,15 +686,14 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     Q[0] = Queue{(float4*)ctx->qbuf[0].p, (float4*)ctx->qbuf[1].p, (float4*)ctx->qbuf[2].p};
     Q[1] = Queue{(float4*)ctx->qbuf[3].p, (float4*)ctx->qbuf[4].p, (float4*)ctx->qbuf[5].p};
     float2* qhit = (float2*)ctx->qhit.p;
-    float* rad = (float*)ctx->rad.p;
+    float4* rad = (float4*)ctx->rad.p;
     float* acc = (float*)ctx->acc.p;
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     unsigned long long* totals = (unsigned long long*)ctx->totals.p; // [0]=tex fetches [1]=bad dirs [2..]=rays per depth
 
     const size_t list_lds = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
     const bool perlin_lds = ctx->ds.n_perlin > 0 && ctx->ds.n_perlin <= RT_PERLIN_LDS_MAX_SETS;
-    const size_t shade_lds = shade_lds_bytes(ctx->ds.n_prims + ctx->ds.n_media, perlin_lds ? ctx->ds.n_perlin : 0u);
-    if (shade_lds > 64u * 1024u) return fail(ctx, RT_ERR_UNSUPPORTED, "render: scene has too many spheres for the k_shade class table");
+    const uint32_t n_plds = perlin_lds ? ctx->ds.n_perlin : 0u;
 
     RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
     RT_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * 3 * sizeof(float), st));
@@ -754,6 +777,9 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
             const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u,
                                  (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u};
+            // sphere geometry for the closest hit inside k_shade<GEN> (candidate lists of a sphere-only scene)
+            const uint32_t n_fused = (gen && !rects && gp.lists) ? ctx->ds.n_spheres : 0u;
+            const size_t shade_lds = shade_lds_bytes(ctx->ds.n_prims + ctx->ds.n_media, n_plds, n_fused, !gen && sp.sort);
 #define RT_LAUNCH_SHADE(P, G, R) \
     hipLaunchKernelGGL((k_shade<P, G, R>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals, gpd)
 #define RT_LAUNCH_SHADE_R(P, G)        \

@@ -112,9 +112,6 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Rng& rng) { // math.rs:17-37
         float z = rng.next();
         V3 v = v3(x, y, z) * (1.0f - -1.0f) + -1.0f;
         if (length_squared(v) < 1.0f) return v;
-#ifdef RT_EXP_ONE_ITER
-        return v; // experiment only (scripts/): cost of the rejection loop's divergence
-#endif
     }
 }
 __device__ __forceinline__ V3 random_on_hemisphere(Rng& rng, V3 n) { // math.rs:43-53
@@ -207,13 +204,14 @@ struct DevScene {
     uint32_t n_images;
     uint32_t sky_type;
     uint32_t sky_image;
+    uint32_t key_miss; // sort key (sph_class) of "no hit"
     uint32_t pad;
     const float4* sph_geo;   // (cx, cy, cz, r)
     const uint32_t* sph_mat;
     const MatRec* mats;
     const TexRec* texs;
     const float4* perlin_vec;   // [n_perlin*256] xyz_
-    const uint8_t* perlin_perm; // [n_perlin*3*256]
+    const unsigned short* perlin_perm2; // [n_perlin*3*256] pairs perm[i] | perm[(i+1) & 255] << 8 (PerlinTables)
     const ImgRec* imgs;
     const float4* texels;       // rgb_
     // LDS-resident 4-wide BVH over the spheres, built at upload (rt_bvh.h HostBvh4): per node one
@@ -223,8 +221,9 @@ struct DevScene {
     uint32_t bvh4_depth;
     const float4* bvh4_p[6];
     const int4* bvh4_id;
-    // shading class of every primitive (1 + material_type*4 + texture_type of tex0; 0 is "miss"):
-    // k_shade sorts the rays of a chunk by class so that a wave runs one material branch
+    // sort key of every world entry: the rank of its shading class (1 + material_type*4 + texture_type of tex0; 0 is
+    // "miss") among the classes present in the scene, cheap classes first.  k_shade orders the hit records of a block
+    // by this key so that a wave runs one material branch.
     const uint8_t* sph_class;
     // Per-primitive shading record, 5 x float4 (one dependent fetch after the hit index instead of
     // primitive -> material -> texture):  [0] sphere: cx cy cz r / rect: k u0 u1 v0
@@ -238,23 +237,26 @@ struct DevScene {
 // ---------------------------------------------------------------------------------------------
 // Perlin table sets: `pvec`/`pperm` point either at the HBM copies in DevScene or at the
 // workgroup's LDS copies (k_shade stages them when they fit, see rt_kernels.h).
+// The permutation tables are stored as PAIRS, perm2[i] = perm[i] | perm[(i + 1) & 255] << 8: a lattice cell needs
+// the entries of i and i + 1 on every axis (texture.rs:103-108), one 16-bit read instead of two byte reads.
 struct PerlinTables {
     const float4* vec;   // [n_sets*256] xyz_
-    const uint8_t* perm; // [n_sets*768] perm_x, perm_y, perm_z
+    const unsigned short* perm; // [n_sets*768] pairs of perm_x, perm_y, perm_z
 };
 __device__ inline float perlin_noise(const PerlinTables& pt, uint32_t set, V3 p) { // texture.rs:125-146, 93-112
     const float4* rv = pt.vec + (size_t)set * 256;
-    const uint8_t* px = pt.perm + (size_t)set * 768;
-    const uint8_t* py = px + 256;
-    const uint8_t* pz = py + 256;
+    const unsigned short* px = pt.perm + (size_t)set * 768;
+    const unsigned short* py = px + 256;
+    const unsigned short* pz = py + 256;
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     int i = (int)fx, j = (int)fy, k = (int)fz;
     V3 uvw = p - v3(fx, fy, fz);
     V3 uvw2 = uvw * uvw * (3.0f - 2.0f * uvw); // math.rs:133-135 smooth
     float u = uvw2.x, v = uvw2.y, w = uvw2.z;
-    uint32_t hx[2] = {px[i & 255], px[(i + 1) & 255]};
-    uint32_t hy[2] = {py[j & 255], py[(j + 1) & 255]};
-    uint32_t hz[2] = {pz[k & 255], pz[(k + 1) & 255]};
+    const uint32_t ex = px[i & 255], ey = py[j & 255], ez = pz[k & 255]; // rem_euclid(256) of i and i + 1
+    uint32_t hx[2] = {ex & 255u, ex >> 8};
+    uint32_t hy[2] = {ey & 255u, ey >> 8};
+    uint32_t hz[2] = {ez & 255u, ez >> 8};
     float accum = 0.0f;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -270,9 +272,6 @@ __device__ inline float perlin_noise(const PerlinTables& pt, uint32_t set, V3 p)
     return accum;
 }
 __device__ inline float perlin_turb(const PerlinTables& pt, uint32_t set, V3 p) { // texture.rs:115-124
-#ifdef RT_EXP_NO_TURB
-    return 0.5f + 0.0f * p.x; // experiment only (scripts/): cost of the 7-octave turbulence
-#endif
     float accum = 0.0f;
     float w = 1.0f;
     for (int it = 0; it < 7; ++it) {

@@ -702,6 +702,12 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 const uint32_t shard = blockIdx.x + k * gridDim.x;
                 pos = (size_t)shard * ip.cap + off;
                 uint4 list = make_uint4(RT_LIST_OVERFLOW, 0u, 0u, 0u);
+                // sphere-only scene with candidate lists: k_shade<GEN> finds the closest hit of a listed pixel itself;
+                // only the rays of pixels whose list overflowed are traced (and recorded) here
+                bool skip = false;
+                if (GEN && !RECTS && gpd->lists)
+                    skip = (gpd->lists[primary_idx_of(ip.nq, shard, off) % gpd->npix].x & 0xFFFFu) != RT_LIST_OVERFLOW;
+                if (!skip) {
                 if (GEN) {
                     uint32_t k0, k1, pl;
                     gen_primary(*gpd, primary_idx_of(ip.nq, shard, off), o, d, k0, k1, pl);
@@ -744,6 +750,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                         has = false;
                     }
                 }
+                } // !skip
             }
         }
         if (!__any(has)) {
@@ -824,27 +831,43 @@ __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float
 struct ShadeParams {
     uint32_t nq, cap;
     int depth, max_depth;
-    uint32_t sort; // 0: process the shard in queue order (depth 0: primary rays are coherent already)
+    uint32_t sort;             // 1: class-sort every 512-ray block before shading it; 0: queue order (depth 0)
     uint32_t russian_roulette; // main.rs:49-53 (commented out in the reference), RT_FLAG_RUSSIAN_ROULETTE
 };
 
-// Shading half of the step: workgroup q owns shard q (reads it, appends survivors to shard q of
-// the output queue through an LDS counter, publishes the new count with a plain store).
+// Shading half of the step: workgroup q owns shard q (reads it, appends survivors to shard q of the output queue
+// through an LDS counter, publishes the new count with a plain store).
 //
-// The 13 material branches and 4 texture kinds diverge badly when a wave holds arbitrary rays
-// (VALU lane utilisation 34 %, profiles/round1).  Rays are therefore processed in super-chunks of
-// RT_SORT_N: a counting sort over the shading class of the hit sphere (DevScene::sph_class; LDS
-// histogram + scan + index permutation, no ray data moves) hands every wave rays of one class,
-// except at class boundaries.  Results do not depend on the processing order.
-// PERLIN_LDS: the Perlin gradient and permutation tables (texture.rs:53-58; 4.75 KB per set) are
-// staged into LDS.
+// The 13 material branches and 4 texture kinds diverge badly when a wave holds arbitrary rays (VALU lane utilisation
+// 34 %, profiles/round1).  From depth 1 on every WAVE therefore takes blocks of RT_SORT_N consecutive rays of the shard
+// and counting-sorts their hit records by shading class (DevScene::sph_class; per-wave LDS histogram, scan over the 64
+// classes by one lane each, sorted records + their queue positions parked in LDS; no ray data moves), then shades the
+// block in class order, 64 rays at a time: a wave runs one material except at class boundaries.  The sort is wave-local
+// on purpose — no workgroup barrier and no second pass over the hit records: past depth 0 this kernel is bound by HBM
+// (profiles/round2: 4.2-4.9 TB/s of FETCH+WRITE with 70 % of the wave-cycles waiting on memory), so the bytes per ray
+// are what counts (8 B hit record + 48 B ray in, 48 B per survivor or 16 B of radiance out) and every wave keeps the
+// next segment's ray gathers in flight while it shades the current one.  Results do not depend on the processing order.
+// (Tried and measured worse, round 2: sorting in k_intersect's epilogue with the order handed over through HBM, +18 B
+// per ray and 3 ms per 128 spp; separate kernels for the cheap and the expensive classes at 8 and 4 waves per SIMD —
+// both kernels fetch nearly every line of a chunk, +50 % bytes; 16 bank-conflict-free copies of the Perlin gradients in
+// LDS — no change: the turbulence is bound by VALU issue, not by its LDS gathers.)
+//
+// PERLIN_LDS: the Perlin gradient and permutation tables (texture.rs:53-58; 5.5 KB per set) are staged into LDS.
+// GEN (depth 0): T = 1, slot = path index, and the ray is regenerated from its queue position.  In sphere-only
+// scenes with candidate lists (k_primary_lists) the closest hit is found right here from the pixel's list — the
+// exact Sphere::hit roots of its <= 7 entries, same winner rule as the tree — so a primary ray is generated once and
+// no hit record travels through HBM; k_intersect<GEN> then only traces the rays of pixels whose list overflowed.
 #define RT_PERLIN_LDS_MAX_SETS 4u
-#define RT_SORT_N 1024u   // rays per counting sort (4 per thread); 2048/4096 measured the same, 8192 slower
+#define RT_SORT_N 512u  // rays per wave-local counting sort (8 segments of 64)
 #define RT_NCLASS 64u
-__host__ __device__ inline size_t shade_lds_bytes(uint32_t n_spheres, uint32_t n_perlin_lds) {
-    size_t b = 16u + RT_NCLASS * 4u * 2u + RT_SORT_N * 2u; // counter, histogram, offsets, permutation
-    b += ((size_t)n_spheres + 15u) & ~(size_t)15u;         // sphere classes
-    b += (size_t)n_perlin_lds * (256u * 16u + 768u);
+#define RT_CLASS_LDS_MAX 4096u // scenes up to this many world entries keep their class table in LDS
+#define RT_SHADE_WAVE_LDS (RT_NCLASS * 4u + RT_SORT_N * 8u + RT_SORT_N * 2u) // histogram, sorted records, positions
+__host__ __device__ inline size_t shade_lds_bytes(uint32_t n_entries, uint32_t n_perlin_lds, uint32_t n_fused_spheres, bool sort) {
+    size_t b = 16u; // survivor counter
+    if (sort) b += 4u * RT_SHADE_WAVE_LDS;
+    if (sort && n_entries <= RT_CLASS_LDS_MAX) b += ((size_t)n_entries + 15u) & ~(size_t)15u;
+    b += (size_t)n_perlin_lds * (4096u + 1536u);
+    b += (size_t)n_fused_spheres * 16u;
     return (b + 15u) & ~(size_t)15u;
 }
 #ifndef RT_SHADE_WAVES
@@ -853,7 +876,7 @@ __host__ __device__ inline size_t shade_lds_bytes(uint32_t n_spheres, uint32_t n
 template <bool PERLIN_LDS, bool GEN, bool RECTS>
 __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
                                                const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,
-                                               float* __restrict__ rad, ShadeParams tp,
+                                               float4* __restrict__ rad, ShadeParams tp,
                                                unsigned long long* __restrict__ stats,
                                                const GenParams* __restrict__ gpd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -861,66 +884,115 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
     const uint32_t count = in_counts[q];
     if (count == 0) return; // out_counts[q] stays 0 (cleared per slice)
     uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + 16);
-    uint32_t* s_offs = s_hist + RT_NCLASS;
-    unsigned short* s_perm = reinterpret_cast<unsigned short*>(s_offs + RT_NCLASS);
-    uint8_t* s_class = reinterpret_cast<uint8_t*>(s_perm + RT_SORT_N);
-    const uint32_t class_bytes = (sc.n_prims + sc.n_media + 15u) & ~15u;
-    for (uint32_t i = threadIdx.x; i < sc.n_prims + sc.n_media; i += 256u) s_class[i] = sc.sph_class[i];
-    PerlinTables pt{sc.perlin_vec, sc.perlin_perm};
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool sort = !GEN && tp.sort != 0u;
+    size_t lds_off = 16u;
+    // this wave's sort scratch
+    uint32_t* s_hist = reinterpret_cast<uint32_t*>(smem + lds_off + (size_t)w * RT_SHADE_WAVE_LDS);
+    float2* s_rec = reinterpret_cast<float2*>(s_hist + RT_NCLASS);
+    unsigned short* s_pos = reinterpret_cast<unsigned short*>(s_rec + RT_SORT_N);
+    const uint8_t* cls = sc.sph_class;
+    if (sort) {
+        lds_off += 4u * RT_SHADE_WAVE_LDS;
+        const uint32_t n_ent = sc.n_prims + sc.n_media;
+        if (n_ent <= RT_CLASS_LDS_MAX) {
+            uint8_t* lc = reinterpret_cast<uint8_t*>(smem + lds_off);
+            for (uint32_t i = threadIdx.x; i < n_ent; i += 256u) lc[i] = sc.sph_class[i];
+            cls = lc;
+            lds_off += ((size_t)n_ent + 15u) & ~(size_t)15u;
+        }
+    }
+    PerlinTables pt{sc.perlin_vec, sc.perlin_perm2};
     if (PERLIN_LDS) {
-        float4* lv = reinterpret_cast<float4*>(s_class + class_bytes);
-        uint8_t* lp = reinterpret_cast<uint8_t*>(lv + sc.n_perlin * 256u);
+        float4* lv = reinterpret_cast<float4*>(smem + lds_off);
+        unsigned short* lp = reinterpret_cast<unsigned short*>(lv + sc.n_perlin * 256u);
         for (uint32_t i = threadIdx.x; i < sc.n_perlin * 256u; i += 256u) lv[i] = sc.perlin_vec[i];
-        for (uint32_t i = threadIdx.x; i < sc.n_perlin * 768u; i += 256u) lp[i] = sc.perlin_perm[i];
-        pt.vec = lv;
-        pt.perm = lp;
+        for (uint32_t i = threadIdx.x; i < sc.n_perlin * 768u; i += 256u) lp[i] = sc.perlin_perm2[i];
+        pt = PerlinTables{lv, lp};
+        lds_off += (size_t)sc.n_perlin * (4096u + 1536u);
+    }
+    // depth 0 with candidate lists in a sphere-only scene: closest hit from the list, sphere geometry in LDS
+    const bool fused = GEN && !RECTS && gpd->lists != nullptr;
+    const float4* s_geo = reinterpret_cast<const float4*>(smem + lds_off);
+    if (fused) {
+        float4* g = reinterpret_cast<float4*>(smem + lds_off);
+        for (uint32_t i = threadIdx.x; i < sc.n_spheres; i += 256u) g[i] = sc.sph_geo[i];
     }
     if (threadIdx.x == 0) *s_out = 0u;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u;
     uint32_t n_fetch = 0, n_bad = 0;
     const size_t qbase = (size_t)q * tp.cap;
-    for (uint32_t base = 0; base < count; base += RT_SORT_N) {
-        const uint32_t n_here = min(RT_SORT_N, count - base);
-        // ---- counting sort of the super-chunk by shading class --------------------------------
-        if (tp.sort) {
-        if (threadIdx.x < RT_NCLASS) s_hist[threadIdx.x] = 0u;
-        __syncthreads();
-        uint32_t cls[4], rank[4];
+    // blocks of RT_SORT_N rays go round-robin to the four waves; a wave never waits for another one.  A short shard
+    // (the deep bounces hold a few hundred rays per shard) is cut into four blocks so that every wave has work.
+    const uint32_t bs = count >= 4u * RT_SORT_N ? RT_SORT_N : ((count + 255u) / 256u) * 64u;
+    for (uint32_t base = w * bs; base < count; base += 4u * bs) {
+        const uint32_t n_here = min(bs, count - base);
+        if (sort) {
+            // ---- wave-local counting sort of the block's hit records by shading class ---------------
+            s_hist[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // LDS operations of one wave complete in order; this
+                                                                   // keeps the compiler from moving them across
+            float2 h[RT_SORT_N / 64u];
+            uint32_t kr[RT_SORT_N / 64u]; // key | rank << 8
 #pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-            const uint32_t j = r * 256u + threadIdx.x;
-            cls[r] = 0u, rank[r] = 0u;
-            if (j < n_here) {
-                const int hit = __float_as_int(qh[qbase + base + j].y);
-                cls[r] = hit < 0 ? 0u : (uint32_t)s_class[hit];
-                rank[r] = atomicAdd(&s_hist[cls[r]], 1u);
+            for (uint32_t k = 0; k < RT_SORT_N / 64u; ++k) {
+                const uint32_t j = k * 64u + lane;
+                h[k] = j < n_here ? qh[qbase + base + j] : make_float2(0.0f, 0.0f);
             }
-        }
-        __syncthreads();
-        if (threadIdx.x < 64u) { // exclusive scan of the 64 class counts by wave 0
-            const uint32_t v = s_hist[threadIdx.x];
-            uint32_t incl = v;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t t = __shfl_up(incl, off);
-                if ((int)lane >= off) incl += t;
+            for (uint32_t k = 0; k < RT_SORT_N / 64u; ++k) {
+                const uint32_t j = k * 64u + lane;
+                kr[k] = 0u;
+                if (j < n_here) {
+                    const int hit = __float_as_int(h[k].y);
+                    const uint32_t key = hit < 0 ? sc.key_miss : (uint32_t)cls[hit];
+                    kr[k] = key | (atomicAdd(&s_hist[key], 1u) << 8);
+                }
             }
-            s_offs[threadIdx.x] = incl - v;
-        }
-        __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            { // exclusive scan of the 64 class counts, one lane per class
+                const uint32_t v = s_hist[lane];
+                uint32_t incl = v;
 #pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-            const uint32_t j = r * 256u + threadIdx.x;
-            if (j < n_here) s_perm[s_offs[cls[r]] + rank[r]] = (unsigned short)j;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = __shfl_up(incl, off);
+                    if ((int)lane >= off) incl += t;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                s_hist[lane] = incl - v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+            for (uint32_t k = 0; k < RT_SORT_N / 64u; ++k) {
+                const uint32_t j = k * 64u + lane;
+                if (j < n_here) {
+                    const uint32_t dst = s_hist[kr[k] & 255u] + (kr[k] >> 8);
+                    s_rec[dst] = h[k];
+                    s_pos[dst] = (unsigned short)j;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
-        __syncthreads();
-        }
-        // ---- shade in class order --------------------------------------------------------------
-        for (uint32_t r = 0; r < 4; ++r) {
-            const uint32_t j = r * 256u + threadIdx.x;
-            if (r * 256u >= n_here) break; // block-uniform
+        // ---- shade the block, 64 rays at a time; the next segment's rays are in flight meanwhile ---------
+        float2 hA = make_float2(0.0f, 0.0f);
+        float4 raA = make_float4(0.f, 0.f, 0.f, 0.f), rbA = raA, rcA = raA;
+        auto fetch = [&](uint32_t seg, float2& h, float4& ra, float4& rb, float4& rc) {
+            const uint32_t j = seg + lane;
+            if (!GEN && j < n_here) {
+                uint32_t pj = j;
+                if (sort) h = s_rec[j], pj = s_pos[j];
+                else h = qh[qbase + base + j];
+                const size_t r = qbase + base + pj;
+                ra = qin.a[r], rb = qin.b[r], rc = qin.c[r];
+            }
+        };
+        fetch(0u, hA, raA, rbA, rcA);
+        for (uint32_t seg = 0; seg < n_here; seg += 64u) {
+            float2 hB = make_float2(0.0f, 0.0f);
+            float4 raB = make_float4(0.f, 0.f, 0.f, 0.f), rbB = raB, rcB = raB;
+            if (seg + 64u < n_here) fetch(seg + 64u, hB, raB, rbB, rcB);
+            const uint32_t j = seg + lane;
             bool alive = false;
             Bounce bo;
             bo.o = bo.d = bo.attenuation = splat(0.0f);
@@ -928,19 +1000,41 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
             float rr_threshold = 0.0f;
             uint32_t slot = 0, k0 = 0, k1 = 0;
             if (j < n_here) {
-                const uint32_t off = base + (tp.sort ? (uint32_t)s_perm[j] : j);
-                const size_t i = qbase + off;
-                const float2 h = qh[i];
+                float2 h = hA;
                 V3 o, d;
-                if (GEN) { // depth 0: T = 1, slot = path index, ray regenerated (bitwise the one k_intersect traced)
-                    slot = primary_idx_of(tp.nq, q, off);
-                    gen_primary(*gpd, slot, o, d, k0, k1);
+                if (GEN) { // depth 0: T = 1, slot = path index, ray regenerated (bitwise the one k_intersect would trace)
+                    uint32_t pl;
+                    slot = primary_idx_of(tp.nq, q, base + j);
+                    gen_primary(*gpd, slot, o, d, k0, k1, pl);
                     T = splat(1.0f);
+                    uint4 list = make_uint4(RT_LIST_OVERFLOW, 0u, 0u, 0u);
+                    if (fused) list = gpd->lists[pl];
+                    const uint32_t n_list = list.x & 0xFFFFu;
+                    if (fused && n_list != RT_LIST_OVERFLOW) {
+                        // leaf_test<false> over the listed entries: Sphere::hit roots (hitable.rs:75-91), order-independent accept
+                        const float a = length_squared(d);
+                        float tbest = RT_FLT_MAX;
+                        int hit = -1;
+                        const uint32_t ids[RT_LIST_MAX] = {list.x >> 16, list.y & 0xFFFFu, list.y >> 16, list.z & 0xFFFFu,
+                                                           list.z >> 16, list.w & 0xFFFFu, list.w >> 16};
+#pragma unroll
+                        for (uint32_t t = 0; t < RT_LIST_MAX; ++t) {
+                            float th;
+                            const int s = (int)ids[t];
+                            if (t < n_list && sphere_root(s_geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th) &&
+                                (th < tbest || (th == tbest && s > hit))) {
+                                tbest = th;
+                                hit = s;
+                            }
+                        }
+                        h = make_float2(tbest, __int_as_float(hit));
+                    } else {
+                        h = qh[qbase + base + j];
+                    }
                 } else {
-                    const float4 ra = qin.a[i], rb = qin.b[i], rc = qin.c[i];
-                    o = v3(ra.x, ra.y, ra.z), d = v3(rb.x, rb.y, rb.z);
-                    T = v3(rc.x, rc.y, rc.z);
-                    slot = __float_as_uint(ra.w), k0 = __float_as_uint(rb.w), k1 = __float_as_uint(rc.w);
+                    o = v3(raA.x, raA.y, raA.z), d = v3(rbA.x, rbA.y, rbA.z);
+                    T = v3(rcA.x, rcA.y, rcA.z);
+                    slot = __float_as_uint(raA.w), k0 = __float_as_uint(rbA.w), k1 = __float_as_uint(rcA.w);
                 }
                 V3 Lr = splat(0.0f);
                 if (!near_one(d)) { // main.rs:39 assert!: the reference panics; the path is dropped
@@ -959,10 +1053,8 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
                         Lr = T * bo.radiance; // L = T_n * (emitted | sky)
                     }
                 }
-                if (!alive) {
-                    float* rp = rad + (size_t)slot * 3u;
-                    rp[0] = Lr.x, rp[1] = Lr.y, rp[2] = Lr.z;
-                }
+                // one 16 B store: beyond depth 0 the slots of a wave are scattered
+                if (!alive) rad[slot] = make_float4(Lr.x, Lr.y, Lr.z, 0.0f);
             }
             // wave64 compaction: ballot + prefix popcount; the wave claims its slots from the LDS counter
             const unsigned long long mask = __ballot(alive);
@@ -981,6 +1073,7 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
                     qout.c[pos] = make_float4(Tn.x, Tn.y, Tn.z, __uint_as_float(k1));
                 }
             }
+            hA = hB, raA = raB, rbA = rbB, rcA = rcB;
         }
     }
     __syncthreads();
@@ -997,16 +1090,16 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
 }
 
 // Sums the slice's samples of each pixel in sample order (main.rs:95-97) onto the running sum.
-__global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ rad, float* __restrict__ acc, uint32_t npix,
+__global__ __launch_bounds__(256) void k_resolve(const float4* __restrict__ rad, float* __restrict__ acc, uint32_t npix,
                                                  uint32_t s_count) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= npix) return;
     float r = acc[3 * (size_t)p], g = acc[3 * (size_t)p + 1], b = acc[3 * (size_t)p + 2];
     for (uint32_t s = 0; s < s_count; ++s) {
-        const float* src = rad + ((size_t)s * npix + p) * 3u;
-        r += src[0];
-        g += src[1];
-        b += src[2];
+        const float4 src = rad[(size_t)s * npix + p];
+        r += src.x;
+        g += src.y;
+        b += src.z;
     }
     acc[3 * (size_t)p] = r, acc[3 * (size_t)p + 1] = g, acc[3 * (size_t)p + 2] = b;
 }
@@ -1102,7 +1195,7 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
     if (!active) return;
     uint32_t n_fetch = 0;
     Rng rng{in_key[2 * i], in_key[2 * i + 1], depth_counter_base(depth)};
-    Bounce bo = shade<true>(sc, PerlinTables{sc.perlin_vec, sc.perlin_perm}, o, d, hit, tbest, rng, n_fetch);
+    Bounce bo = shade<true>(sc, PerlinTables{sc.perlin_vec, sc.perlin_perm2}, o, d, hit, tbest, rng, n_fetch);
     out_hit[i] = hit;
     out_t[i] = hit >= 0 ? tbest : 0.0f;
     out_rad[3 * i] = bo.radiance.x, out_rad[3 * i + 1] = bo.radiance.y, out_rad[3 * i + 2] = bo.radiance.z;
