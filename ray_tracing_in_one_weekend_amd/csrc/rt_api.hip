@@ -32,6 +32,8 @@ struct DevBuf {
 struct RtCtx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // second shard group of a slice (render_impl)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     // scene
     bool has_scene = false;
@@ -188,6 +190,9 @@ int rt_ctx_create(int device_id, RtCtx** out_ctx) {
             if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_limit)) != hipSuccess)
                 return bail("hipFuncSetAttribute(MaxDynamicSharedMemorySize)", e);
     }
+    if ((e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail("hipEventCreate", e);
     *out_ctx = ctx;
@@ -198,6 +203,7 @@ void rt_ctx_destroy(RtCtx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     free_scene(ctx);
     for (auto& b : ctx->qbuf) free_buf(b);
     free_buf(ctx->rad), free_buf(ctx->acc), free_buf(ctx->counts), free_buf(ctx->totals);
@@ -207,6 +213,9 @@ void rt_ctx_destroy(RtCtx* ctx) {
     for (auto ev : ctx->depth_events) (void)hipEventDestroy(ev);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -629,8 +638,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t npix = (uint32_t)npix64;
     // slice size: few, large slices amortise the short-queue tail of the bounce loop (depths > ~12 hold a few
     // thousand rays) — config 2 measured 99 / 88 / 82 / 79.5 ms per frame with 8 / 4 / 2 / 1 slices.  A ray of
-    // the slice costs 120 B of work buffers (two 48 B queues, 8 B hit record, 16 B radiance slot): up to 640 Mi
-    // rays (74 GiB of the 288 GB HBM), less when the device has less memory to give.
+    // the slice costs 104 B of work buffers (two 40 B queues, 8 B hit record, 16 B radiance slot): up to 640 Mi
+    // rays (65 GiB of the 288 GB HBM), less when the device has less memory to give.
     uint32_t S = prm->spp_slice;
     if (S == 0) {
         uint64_t max_rays = 640ull << 20;
@@ -638,7 +647,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             size_t held = ctx->rad.bytes + ctx->qhit.bytes;
             for (const DevBuf& b : ctx->qbuf) held += b.bytes;
-            max_rays = std::min<uint64_t>(max_rays, (uint64_t)((double)(free_b + held) * 0.5 / 120.0));
+            max_rays = std::min<uint64_t>(max_rays, (uint64_t)((double)(free_b + held) * 0.5 / 104.0));
         }
         S = (uint32_t)std::max<uint64_t>(1, max_rays / npix64);
     }
@@ -666,8 +675,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t cap = ((nchunks + nq - 1) / nq) * 256u;
 
     const size_t qbytes = (size_t)nq * cap * sizeof(float4);
-    for (auto& b : ctx->qbuf)
-        if ((rc = ensure(ctx, b, qbytes))) return rc;
+    for (int k = 0; k < 6; ++k)
+        if ((rc = ensure(ctx, ctx->qbuf[k], k % 3 == 2 ? qbytes / 2 : qbytes))) return rc;
     if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
     if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * sizeof(float4)))) return rc;
     if ((rc = ensure(ctx, ctx->acc, (size_t)npix * 3 * sizeof(float)))) return rc;
@@ -683,8 +692,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         ctx->events.push_back(ev);
     }
     Queue Q[2];
-    Q[0] = Queue{(float4*)ctx->qbuf[0].p, (float4*)ctx->qbuf[1].p, (float4*)ctx->qbuf[2].p};
-    Q[1] = Queue{(float4*)ctx->qbuf[3].p, (float4*)ctx->qbuf[4].p, (float4*)ctx->qbuf[5].p};
+    Q[0] = Queue{(float4*)ctx->qbuf[0].p, (float4*)ctx->qbuf[1].p, (float2*)ctx->qbuf[2].p};
+    Q[1] = Queue{(float4*)ctx->qbuf[3].p, (float4*)ctx->qbuf[4].p, (float2*)ctx->qbuf[5].p};
     float2* qhit = (float2*)ctx->qhit.p;
     float4* rad = (float4*)ctx->rad.p;
     float* acc = (float*)ctx->acc.p;
@@ -711,6 +720,10 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     gp.nq = nq, gp.cap = cap;
     gp.seed_lo = (uint32_t)prm->seed, gp.seed_hi = (uint32_t)(prm->seed >> 32);
     gp.lists = nullptr;
+    {   // udiv_inv: reciprocals that keep the float quotient at or below the true one
+        auto inv = [](uint32_t d) { return (float)((1.0 / (double)d) * (1.0 - 1.0 / 4194304.0)); };
+        gp.inv_npix = inv(npix), gp.inv_nx = inv(nx), gp.inv_band = inv(band);
+    }
     // Candidate lists of the primary rays, once per frame (k_primary_lists): worth it when the samples of a pixel
     // share them (>= 4 spp) and pixels see few entries.  Measured per 128-spp slice: sphere_scene (533 entries)
     // 46.7 -> 41.9 ms, pbr_sweep_scene 41.2 -> 39.3, test_sphere 15.5 -> 14.8, cornell_box unchanged (its walls'
@@ -733,7 +746,16 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             ctx->depth_events.push_back(ev);
         }
     }
-    IntersectParams ip{nq, cap, 0};
+    IntersectParams ip{nq, cap, 0, 0u, nq};
+    // Two shard groups on two streams: k_intersect is bound by VALU issue and leaves HBM idle, k_shade past depth 0
+    // waits on HBM and leaves the VALUs idle (profiles/round2).  Each half of the shards runs its own chain
+    // intersect -> shade -> intersect ... on its own stream; the two chains drift apart because the kernels differ in
+    // length, and the dispatcher fills every CU with waves of both kinds.  Same kernels, same results; config 2 runs
+    // 2 % faster than with one chain over all shards (forcing the two chains half a step apart with events, so that one
+    // always intersects while the other shades, was 12 % SLOWER: half-size grids in lockstep).  Per-depth timing
+    // needs the single chain.
+    const uint32_t n_groups = (nq >= 2u * RT_ISECT_MAX_SHARDS && !time_depths && !getenv("RTOW_ONE_STREAM")) ? 2u : 1u;
+    const uint32_t shards_per_wg = (nq + isect_grid - 1u) / isect_grid;
     // selects the "general scene" kernel instantiations (rectangles and Translate / RotateY wrappers)
     const bool rects = ctx->ds.n_rects > 0 || ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0;
     for (uint32_t sl = 0; sl < n_slices; ++sl) {
@@ -745,7 +767,15 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         hipLaunchKernelGGL(k_init_counts, dim3((nq + 255u) / 256u), dim3(256), 0, st, gp, counts, gpd);
         if (!fuse_gen) hipLaunchKernelGGL(k_gen_primary, dim3((gp.n_rays + 255u) / 256u), dim3(256), 0, st, gp, Q[0]);
         RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl], st));
-        for (int depth = 0; depth < n_depths; ++depth) {
+        if (n_groups > 1u) {
+            RT_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        }
+        for (int depth = 0; depth < n_depths; ++depth)
+        for (uint32_t grp = 0; grp < n_groups; ++grp) {
+            hipStream_t sg = grp ? ctx->stream2 : st;
+            const uint32_t q0 = grp * (nq / n_groups), q1 = grp + 1u == n_groups ? nq : q0 + nq / n_groups;
+            const uint32_t isect_grid_g = (q1 - q0 + shards_per_wg - 1u) / shards_per_wg;
             const Queue& qi = Q[depth & 1];
             const Queue& qo = Q[(depth + 1) & 1];
             const uint32_t* cin = counts + (size_t)depth * nq;
@@ -754,9 +784,10 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth], st));
             const bool gen = fuse_gen && depth == 0;
             ip.depth = depth;
+            ip.q0 = q0, ip.q1 = q1;
 #define RT_LAUNCH_ISECT(G, R, N, T)                                                                                    \
-    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R, N, T>), dim3(isect_grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, st, ctx->ds, \
-                       qi.a, qi.b, qi.c, qhit, cin, ip, gpd)
+    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R, N, T>), dim3(isect_grid_g), dim3(RT_BVH_BLOCK), ctx->isect_lds, sg, ctx->ds, \
+                       qi.a, qi.b, qhit, cin, ip, gpd)
 #define RT_LAUNCH_ISECT_G(G, N)                       \
     do {                                              \
         if (ctx->general_lds) RT_LAUNCH_ISECT(G, true, N, true); \
@@ -772,16 +803,16 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
 #undef RT_LAUNCH_ISECT_G
 #undef RT_LAUNCH_ISECT
             else
-                hipLaunchKernelGGL(k_intersect_list, dim3(nq), dim3(256), list_lds, st, ctx->ds, qi.a, qi.b, qi.c, qhit, cin, ip);
+                hipLaunchKernelGGL(k_intersect_list, dim3(q1 - q0), dim3(256), list_lds, sg, ctx->ds, qi.a, qi.b, qhit, cin, ip, gpd);
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth + 1], st));
             // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
             const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u,
-                                 (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u};
+                                 (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u, q0};
             // sphere geometry for the closest hit inside k_shade<GEN> (candidate lists of a sphere-only scene)
             const uint32_t n_fused = (gen && !rects && gp.lists) ? ctx->ds.n_spheres : 0u;
             const size_t shade_lds = shade_lds_bytes(ctx->ds.n_prims + ctx->ds.n_media, n_plds, n_fused, !gen && sp.sort);
 #define RT_LAUNCH_SHADE(P, G, R) \
-    hipLaunchKernelGGL((k_shade<P, G, R>), dim3(nq), dim3(256), shade_lds, st, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals, gpd)
+    hipLaunchKernelGGL((k_shade<P, G, R>), dim3(q1 - q0), dim3(256), shade_lds, sg, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals, gpd)
 #define RT_LAUNCH_SHADE_R(P, G)        \
     do {                               \
         if (rects) RT_LAUNCH_SHADE(P, G, true); \
@@ -794,6 +825,10 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
 #undef RT_LAUNCH_SHADE_R
 #undef RT_LAUNCH_SHADE
             n_trace_launches += 2;
+        }
+        if (n_groups > 1u) {
+            RT_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
         }
         if (time_depths && sl == 0) {
             RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)n_depths], st));

@@ -13,12 +13,15 @@
 //   k_resolve        : main.rs:95-98 sample sum in sample order
 //   k_finalize       : main.rs:98-105,127 /spp, gamma 2, *255.99 as u8, vertical flip
 //
-// Ray queue layout in HBM ("SoA of float4", 48 B per ray, 16 B per lane per load so that one
-// wave instruction moves 1 KiB contiguous), plus an 8 B hit record per ray between the kernels:
+// Ray queue layout in HBM (SoA, 40 B per ray: two 16 B arrays that k_intersect reads and an 8 B one that only
+// k_shade needs), plus an 8 B hit record per ray between the kernels:
 //   qa[i] = (o.x, o.y, o.z, slot)   slot = path slot of the slice = s_local * npix + pixel_local
-//   qb[i] = (d.x, d.y, d.z, k0)     (k0,k1) = per-path RNG key
-//   qc[i] = (T.x, T.y, T.z, k1)     T = path throughput
-//   qh[i] = (t, sphere index)       written by k_intersect, read by k_shade
+//   qb[i] = (d.x, d.y, d.z, T.x)    T = path throughput
+//   qc[i] = (T.y, T.z)
+//   qh[i] = (t, entry index)        written by k_intersect, read by k_shade
+// The per-path RNG key (k0, k1) is a pure function of (seed, pixel, sample), i.e. of the slot: it is recomputed
+// where it is needed (path_key_of_slot, ~60 instructions) instead of travelling with the ray — past depth 0 k_shade is
+// bound by HBM bytes, 8 B less per ray read and per survivor written.
 // The queue is cut into `nq` shards of capacity `cap` rays.  Shard q is read and appended to by
 // exactly ONE workgroup per kernel (k_shade: workgroup q; k_intersect: workgroup q % gridDim), so
 // queue positions come from an LDS counter: the bounce loop issues no global atomics at all.
@@ -32,7 +35,7 @@ namespace rt {
 struct Queue {
     float4* a;
     float4* b;
-    float4* c;
+    float2* c;
 };
 
 struct GenParams {
@@ -45,11 +48,37 @@ struct GenParams {
     uint32_t nq, cap;
     uint32_t seed_lo, seed_hi;
     const uint4* lists;   // per-pixel candidate lists of the primary rays (k_primary_lists) or NULL
+    float inv_npix, inv_nx, inv_band; // reciprocals rounded towards zero by 2^-22 (udiv_inv)
 };
 
 __device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t band, uint32_t count, uint32_t id) {
     if (count <= 1) return lj;
     return ((lj / band) * count + id) * band + (lj % band);
+}
+
+// x / d for the slot arithmetic below (quotients below 2^21): a float product that never exceeds the true quotient
+// (inv = (1/d)(1 - 2^-22) absorbs the roundings of the conversion and of the product) and two correction steps.
+__device__ __forceinline__ uint32_t udiv_inv(uint32_t x, uint32_t d, float inv, uint32_t& rem) {
+    uint32_t qt = (uint32_t)((float)x * inv);
+    uint32_t r = x - qt * d;
+    if (r >= d) ++qt, r -= d;
+    if (r >= d) ++qt, r -= d;
+    rem = r;
+    return qt;
+}
+// RNG key of the path in slot `slot` of the slice: the inverse of slot = s_local * npix + pixel_local, then path_key
+// exactly as gen_primary computes it.
+__device__ __forceinline__ void path_key_of_slot(const GenParams& gp, uint32_t slot, uint32_t& k0, uint32_t& k1) {
+    uint32_t pl, i;
+    const uint32_t s_local = udiv_inv(slot, gp.npix, gp.inv_npix, pl);
+    const uint32_t lj = udiv_inv(pl, gp.nx, gp.inv_nx, i);
+    uint32_t j = lj;
+    if (gp.shard_count > 1u) {
+        uint32_t rb;
+        const uint32_t bq = udiv_inv(lj, gp.shard_band, gp.inv_band, rb);
+        j = (bq * gp.shard_count + gp.shard_id) * gp.shard_band + rb;
+    }
+    path_key(((uint64_t)gp.seed_hi << 32) | gp.seed_lo, j * gp.nx + i, gp.s0 + s_local, k0, k1);
 }
 
 // Primary ray of path `idx` of the slice (main.rs:86-94 + camera.rs:40-46).
@@ -116,8 +145,8 @@ __global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q) {
     const uint32_t sq = chunk % gp.nq;
     const size_t pos = (size_t)sq * gp.cap + (size_t)(chunk / gp.nq) * 256u + (idx & 255u);
     q.a[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(idx));
-    q.b[pos] = make_float4(d.x, d.y, d.z, __uint_as_float(k0));
-    q.c[pos] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(k1));
+    q.b[pos] = make_float4(d.x, d.y, d.z, 1.0f);
+    q.c[pos] = make_float2(1.0f, 1.0f);
 }
 
 // Candidate lists of the primary rays.  All samples of a pixel leave the camera through the pixel's footprint
@@ -635,9 +664,10 @@ __device__ __forceinline__ bool media_step(const BvhLds& L, V3 o, V3 d, const Me
 struct IntersectParams {
     uint32_t nq, cap;
     int depth;
+    uint32_t q0, q1; // this launch covers the shards [q0, q1) (one of the two shard groups, rt_api.hip)
 };
 
-// Closest hit for every queued ray of the shards q = blockIdx.x, blockIdx.x + gridDim.x, ...
+// Closest hit for every queued ray of the shards q = q0 + blockIdx.x, q0 + blockIdx.x + gridDim.x, ... below q1
 // Persistent lanes: a lane whose traversal has finished writes its hit record and, once enough
 // lanes of the wave are idle, the wave claims that many fresh rays from the workgroup's LDS work
 // counter (the shards of the workgroup are concatenated into one virtual index space).  With no
@@ -648,7 +678,7 @@ struct IntersectParams {
 // GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
 template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES, bool GLDS>
 __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float4* __restrict__ qa,
-                                                     const float4* __restrict__ qb, const float4* __restrict__ qc,
+                                                     const float4* __restrict__ qb,
                                                      float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
                                                      IntersectParams ip, const GenParams* __restrict__ gpd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -658,10 +688,10 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
     uint32_t n_my = 0;
 #pragma unroll
     for (uint32_t k = 0; k < RT_ISECT_MAX_SHARDS; ++k) {
-        const uint32_t q = blockIdx.x + k * gridDim.x;
-        const uint32_t c = q < ip.nq ? in_counts[q] : 0u;
+        const uint32_t q = ip.q0 + blockIdx.x + k * gridDim.x;
+        const uint32_t c = q < ip.q1 ? in_counts[q] : 0u;
         pre[k + 1] = pre[k] + c;
-        if (q < ip.nq) n_my = k + 1;
+        if (q < ip.q1) n_my = k + 1;
     }
     const uint32_t total = pre[RT_ISECT_MAX_SHARDS];
     if (total == 0) return; // block-uniform
@@ -699,7 +729,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 uint32_t off = v;
 #pragma unroll
                 for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) off = (k == t) ? v - pre[t] : off;
-                const uint32_t shard = blockIdx.x + k * gridDim.x;
+                const uint32_t shard = ip.q0 + blockIdx.x + k * gridDim.x;
                 pos = (size_t)shard * ip.cap + off;
                 uint4 list = make_uint4(RT_LIST_OVERFLOW, 0u, 0u, 0u);
                 // sphere-only scene with candidate lists: k_shade<GEN> finds the closest hit of a listed pixel itself;
@@ -717,7 +747,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                     const float4 ra = qa[pos], rb = qb[pos];
                     o = v3(ra.x, ra.y, ra.z);
                     d = v3(rb.x, rb.y, rb.z);
-                    if (RECTS && sc.n_media) mc.k0 = __float_as_uint(rb.w), mc.k1 = __float_as_uint(qc[pos].w);
+                    if (RECTS && sc.n_media) path_key_of_slot(*gpd, __float_as_uint(ra.w), mc.k0, mc.k1); // the free-path draw
                 }
                 ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
                 nox = -(o.x * ix), noy = -(o.y * iy), noz = -(o.z * iz);
@@ -781,12 +811,12 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
 
 // List-walk closest hit: one workgroup per shard, sphere list streamed through LDS tiles.
 __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float4* __restrict__ qa,
-                                                        const float4* __restrict__ qb, const float4* __restrict__ qc,
+                                                        const float4* __restrict__ qb,
                                                         float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
-                                                        IntersectParams ip) {
+                                                        IntersectParams ip, const GenParams* __restrict__ gpd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_geo = reinterpret_cast<float4*>(smem);
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = ip.q0 + blockIdx.x;
     const uint32_t count = in_counts[q];
     if (count == 0) return;
     const uint32_t n_sph = sc.n_spheres;
@@ -822,7 +852,7 @@ __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float
             }
         }
         MediumCtx mc{0u, 0u, depth_counter_base(ip.depth)};
-        if (active && sc.n_media) mc.k0 = __float_as_uint(qb[qbase + i].w), mc.k1 = __float_as_uint(qc[qbase + i].w);
+        if (active && sc.n_media) path_key_of_slot(*gpd, __float_as_uint(qa[qbase + i].w), mc.k0, mc.k1);
         closest_hit_rects(sc, o, d, mc, tbest, hit);
         if (active) qh[qbase + i] = make_float2(tbest, __int_as_float(hit));
     }
@@ -833,6 +863,7 @@ struct ShadeParams {
     int depth, max_depth;
     uint32_t sort;             // 1: class-sort every 512-ray block before shading it; 0: queue order (depth 0)
     uint32_t russian_roulette; // main.rs:49-53 (commented out in the reference), RT_FLAG_RUSSIAN_ROULETTE
+    uint32_t q0;               // first shard of this launch (shard groups, rt_api.hip)
 };
 
 // Shading half of the step: workgroup q owns shard q (reads it, appends survivors to shard q of the output queue
@@ -850,7 +881,8 @@ struct ShadeParams {
 // (Tried and measured worse, round 2: sorting in k_intersect's epilogue with the order handed over through HBM, +18 B
 // per ray and 3 ms per 128 spp; separate kernels for the cheap and the expensive classes at 8 and 4 waves per SIMD —
 // both kernels fetch nearly every line of a chunk, +50 % bytes; 16 bank-conflict-free copies of the Perlin gradients in
-// LDS — no change: the turbulence is bound by VALU issue, not by its LDS gathers.)
+// LDS — no change: the turbulence is bound by VALU issue, not by its LDS gathers; an instantiation without the pbr.rs
+// materials at 96 VGPRs / 5 waves per SIMD for scenes that use none — no change.)
 //
 // PERLIN_LDS: the Perlin gradient and permutation tables (texture.rs:53-58; 5.5 KB per set) are staged into LDS.
 // GEN (depth 0): T = 1, slot = path index, and the ray is regenerated from its queue position.  In sphere-only
@@ -870,17 +902,14 @@ __host__ __device__ inline size_t shade_lds_bytes(uint32_t n_entries, uint32_t n
     b += (size_t)n_fused_spheres * 16u;
     return (b + 15u) & ~(size_t)15u;
 }
-#ifndef RT_SHADE_WAVES
-#define RT_SHADE_WAVES 4
-#endif
 template <bool PERLIN_LDS, bool GEN, bool RECTS>
-__global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
+__global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
                                                const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,
                                                float4* __restrict__ rad, ShadeParams tp,
                                                unsigned long long* __restrict__ stats,
                                                const GenParams* __restrict__ gpd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = tp.q0 + blockIdx.x;
     const uint32_t count = in_counts[q];
     if (count == 0) return; // out_counts[q] stays 0 (cleared per slice)
     uint32_t* s_out = reinterpret_cast<uint32_t*>(smem);
@@ -975,9 +1004,9 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
         // ---- shade the block, 64 rays at a time; the next segment's rays are in flight meanwhile ---------
-        float2 hA = make_float2(0.0f, 0.0f);
-        float4 raA = make_float4(0.f, 0.f, 0.f, 0.f), rbA = raA, rcA = raA;
-        auto fetch = [&](uint32_t seg, float2& h, float4& ra, float4& rb, float4& rc) {
+        float2 hA = make_float2(0.0f, 0.0f), rcA = hA;
+        float4 raA = make_float4(0.f, 0.f, 0.f, 0.f), rbA = raA;
+        auto fetch = [&](uint32_t seg, float2& h, float4& ra, float4& rb, float2& rc) {
             const uint32_t j = seg + lane;
             if (!GEN && j < n_here) {
                 uint32_t pj = j;
@@ -989,8 +1018,8 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
         };
         fetch(0u, hA, raA, rbA, rcA);
         for (uint32_t seg = 0; seg < n_here; seg += 64u) {
-            float2 hB = make_float2(0.0f, 0.0f);
-            float4 raB = make_float4(0.f, 0.f, 0.f, 0.f), rbB = raB, rcB = raB;
+            float2 hB = make_float2(0.0f, 0.0f), rcB = hB;
+            float4 raB = make_float4(0.f, 0.f, 0.f, 0.f), rbB = raB;
             if (seg + 64u < n_here) fetch(seg + 64u, hB, raB, rbB, rcB);
             const uint32_t j = seg + lane;
             bool alive = false;
@@ -1033,8 +1062,9 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
                     }
                 } else {
                     o = v3(raA.x, raA.y, raA.z), d = v3(rbA.x, rbA.y, rbA.z);
-                    T = v3(rcA.x, rcA.y, rcA.z);
-                    slot = __float_as_uint(raA.w), k0 = __float_as_uint(rbA.w), k1 = __float_as_uint(rcA.w);
+                    T = v3(rbA.w, rcA.x, rcA.y);
+                    slot = __float_as_uint(raA.w);
+                    path_key_of_slot(*gpd, slot, k0, k1);
                 }
                 V3 Lr = splat(0.0f);
                 if (!near_one(d)) { // main.rs:39 assert!: the reference panics; the path is dropped
@@ -1069,8 +1099,8 @@ __global__ __launch_bounds__(256, RT_SHADE_WAVES) void k_shade(DevScene sc, Queu
                     V3 Tn = T * bo.attenuation;
                     if (tp.russian_roulette) Tn = Tn / rr_threshold; // (T * a) / threshold
                     qout.a[pos] = make_float4(bo.o.x, bo.o.y, bo.o.z, __uint_as_float(slot));
-                    qout.b[pos] = make_float4(bo.d.x, bo.d.y, bo.d.z, __uint_as_float(k0));
-                    qout.c[pos] = make_float4(Tn.x, Tn.y, Tn.z, __uint_as_float(k1));
+                    qout.b[pos] = make_float4(bo.d.x, bo.d.y, bo.d.z, Tn.x);
+                    qout.c[pos] = make_float2(Tn.y, Tn.z);
                 }
             }
             hA = hB, raA = raB, rbA = rbB, rcA = rcB;
