@@ -225,6 +225,12 @@ typedef struct RtParams {
 /* Record HIP events around the kernels of every depth of the FIRST slice; read them back with
  * rt_get_depth_timings().  Diagnostic only (adds two event records per depth). */
 #define RT_FLAG_TIME_DEPTHS 4u
+/* rt_debug_bounce only: run the rays through the ray queue and the SAME kernels rt_render launches for a depth >= 1
+ * (the scene's closest-hit kernel with persistent lanes, then the class-sorting shading kernel with its wave64
+ * compaction) instead of the unsorted single-kernel test path.  The per-path RNG key is then the one the renderer
+ * derives from the slot: ray i gets path_key(seed 0, pixel i, sample 0) and in_key is ignored; out_attenuation,
+ * out_o and out_d are filled for surviving rays only (a finished path keeps no ray), out_radiance for finished ones. */
+#define RT_FLAG_PRODUCTION_KERNELS 8u
 
 typedef struct RtStats {
     uint64_t n_paths;          /* nx_rows_local * nx * spp                                   */

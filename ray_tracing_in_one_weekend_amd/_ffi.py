@@ -16,6 +16,7 @@ RT_NO_TEX = 0xFFFFFFFF
 FLAG_BRUTE_FORCE = 1
 FLAG_RUSSIAN_ROULETTE = 2
 FLAG_TIME_DEPTHS = 4
+FLAG_PRODUCTION_KERNELS = 8  # rt_debug_bounce through the ray queue and the kernels rt_render launches
 RTH_INVALID = 0xFFFFFFFF
 
 # enum RtMatType

@@ -128,6 +128,88 @@ bool class_is_light(uint32_t cls, uint32_t sky_type) {
     return tt == RT_TEX_CONSTANT && ty <= RT_MAT_ISOTROPIC;
 }
 
+
+// ---- the two trace-step launches (render_impl and the production-kernel test hook share them) ----------------
+struct StepBuffers {
+    Queue qi, qo;
+    float2* qhit;
+    const uint32_t* cin;
+    uint32_t* cout;
+    float4* rad;
+    unsigned long long* totals;
+    const GenParams* gpd;
+};
+bool scene_is_general(const RtCtx* ctx) { return ctx->ds.n_rects > 0 || ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0; }
+bool scene_perlin_lds(const RtCtx* ctx) { return ctx->ds.n_perlin > 0 && ctx->ds.n_perlin <= RT_PERLIN_LDS_MAX_SETS; }
+
+// closest hit of the shards [ip.q0, ip.q1): the tree instantiation that matches the scene, or the list walk
+void launch_intersect(RtCtx* ctx, hipStream_t sg, bool use_bvh, bool gen, uint32_t grid, const StepBuffers& b, const IntersectParams& ip) {
+    const bool rects = scene_is_general(ctx);
+#define RT_LAUNCH_ISECT(G, R, N, T)                                                                                    \
+    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R, N, T>), dim3(grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, sg, ctx->ds, \
+                       b.qi.a, b.qi.b, b.qhit, b.cin, ip, b.gpd)
+#define RT_LAUNCH_ISECT_G(G, N)                       \
+    do {                                              \
+        if (ctx->general_lds) RT_LAUNCH_ISECT(G, true, N, true); \
+        else RT_LAUNCH_ISECT(G, true, N, false);      \
+    } while (0)
+    // trees that do not fit LDS use the general instantiation (R = true works for sphere-only scenes too)
+    if (use_bvh && !ctx->bvh_in_lds && gen) RT_LAUNCH_ISECT_G(true, false);
+    else if (use_bvh && !ctx->bvh_in_lds) RT_LAUNCH_ISECT_G(false, false);
+    else if (use_bvh && gen && rects) RT_LAUNCH_ISECT_G(true, true);
+    else if (use_bvh && gen) RT_LAUNCH_ISECT(true, false, true, false);
+    else if (use_bvh && rects) RT_LAUNCH_ISECT_G(false, true);
+    else if (use_bvh) RT_LAUNCH_ISECT(false, false, true, false);
+#undef RT_LAUNCH_ISECT_G
+#undef RT_LAUNCH_ISECT
+    else {
+        const size_t list_lds = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
+        hipLaunchKernelGGL(k_intersect_list, dim3(ip.q1 - ip.q0), dim3(256), list_lds, sg, ctx->ds, b.qi.a, b.qi.b, b.qhit, b.cin, ip, b.gpd);
+    }
+}
+
+// shading of the shards [sp.q0, sp.q0 + n_shards); `fused_lists`: depth 0 of a sphere-only scene with candidate lists
+void launch_shade(RtCtx* ctx, hipStream_t sg, bool gen, bool fused_lists, uint32_t n_shards, const StepBuffers& b, const ShadeParams& sp) {
+    const bool rects = scene_is_general(ctx), perlin_lds = scene_perlin_lds(ctx);
+    // sphere geometry for the closest hit inside k_shade<GEN>
+    const uint32_t n_fused = (gen && fused_lists) ? ctx->ds.n_spheres : 0u;
+    const size_t shade_lds = shade_lds_bytes(ctx->ds.n_prims + ctx->ds.n_media, perlin_lds ? ctx->ds.n_perlin : 0u, n_fused, !gen && sp.sort);
+#define RT_LAUNCH_SHADE(P, G, R) \
+    hipLaunchKernelGGL((k_shade<P, G, R>), dim3(n_shards), dim3(256), shade_lds, sg, ctx->ds, b.qi, b.qhit, b.qo, b.cin, b.cout, b.rad, sp, b.totals, b.gpd)
+#define RT_LAUNCH_SHADE_R(P, G)        \
+    do {                               \
+        if (rects) RT_LAUNCH_SHADE(P, G, true); \
+        else RT_LAUNCH_SHADE(P, G, false);      \
+    } while (0)
+    if (perlin_lds && gen) RT_LAUNCH_SHADE_R(true, true);
+    else if (perlin_lds) RT_LAUNCH_SHADE_R(true, false);
+    else if (gen) RT_LAUNCH_SHADE_R(false, true);
+    else RT_LAUNCH_SHADE_R(false, false);
+#undef RT_LAUNCH_SHADE_R
+#undef RT_LAUNCH_SHADE
+}
+
+// Queue geometry of a slice of n_max rays: shard count, k_intersect grid, shard capacity.
+struct QueueGeom {
+    uint32_t nq, isect_grid, cap;
+};
+QueueGeom queue_geom(const RtCtx* ctx, uint32_t n_max) {
+    QueueGeom g;
+    // Queue shards: one per k_shade workgroup (8 workgroups of 256 threads per CU), each owned by one
+    // workgroup per kernel so that queue positions come from LDS counters (rt_kernels.h).
+    g.nq = (uint32_t)ctx->n_cu * 8u;
+    if (const char* e = getenv("RTOW_NQ")) g.nq = (uint32_t)std::max(1, atoi(e)); // experiment knob (scripts/)
+    // k_intersect: as many 1024-thread workgroups per CU as LDS admits (two at <= 64 VGPRs); every
+    // workgroup owns nq / isect_grid shards
+    const uint32_t isect_wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_limit / std::max<size_t>(ctx->isect_lds, 1)));
+    g.isect_grid = std::min(g.nq, (uint32_t)ctx->n_cu * isect_wg_per_cu);
+    while ((g.nq + g.isect_grid - 1) / g.isect_grid > RT_ISECT_MAX_SHARDS) g.isect_grid *= 2;
+    g.isect_grid = std::min(g.isect_grid, g.nq);
+    const uint32_t nchunks = (n_max + 255u) / 256u;
+    g.cap = ((nchunks + g.nq - 1) / g.nq) * 256u;
+    return g;
+}
+
 } // namespace
 
 extern "C" {
@@ -658,21 +740,11 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t n_max = npix * S;
     const int n_depths = prm->max_depth + 1;
 
-    // Queue shards: one per k_shade workgroup (8 workgroups of 256 threads per CU), each owned by one
-    // workgroup per kernel so that queue positions come from LDS counters (rt_kernels.h).
-    uint32_t nq = (uint32_t)ctx->n_cu * 8u;
-    if (const char* e = getenv("RTOW_NQ")) nq = (uint32_t)std::max(1, atoi(e)); // experiment knob (scripts/)
+    const QueueGeom qg = queue_geom(ctx, n_max);
+    const uint32_t nq = qg.nq, isect_grid = qg.isect_grid, cap = qg.cap;
     const bool use_bvh = ctx->use_bvh && !(prm->flags & RT_FLAG_BRUTE_FORCE);
     // depth 0 regenerates the primary ray in both kernels instead of materialising the queue
     const bool fuse_gen = use_bvh && !getenv("RTOW_NO_FUSE_GEN");
-    // k_intersect: as many 1024-thread workgroups per CU as LDS admits (two at <= 64 VGPRs); every
-    // workgroup owns nq / isect_grid shards
-    const uint32_t isect_wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_limit / std::max<size_t>(ctx->isect_lds, 1)));
-    uint32_t isect_grid = std::min(nq, (uint32_t)ctx->n_cu * isect_wg_per_cu);
-    while ((nq + isect_grid - 1) / isect_grid > RT_ISECT_MAX_SHARDS) isect_grid *= 2;
-    isect_grid = std::min(isect_grid, nq);
-    const uint32_t nchunks = (n_max + 255u) / 256u;
-    const uint32_t cap = ((nchunks + nq - 1) / nq) * 256u;
 
     const size_t qbytes = (size_t)nq * cap * sizeof(float4);
     for (int k = 0; k < 6; ++k)
@@ -699,10 +771,6 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     float* acc = (float*)ctx->acc.p;
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     unsigned long long* totals = (unsigned long long*)ctx->totals.p; // [0]=tex fetches [1]=bad dirs [2..]=rays per depth
-
-    const size_t list_lds = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
-    const bool perlin_lds = ctx->ds.n_perlin > 0 && ctx->ds.n_perlin <= RT_PERLIN_LDS_MAX_SETS;
-    const uint32_t n_plds = perlin_lds ? ctx->ds.n_perlin : 0u;
 
     RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
     RT_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * 3 * sizeof(float), st));
@@ -757,7 +825,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t n_groups = (nq >= 2u * RT_ISECT_MAX_SHARDS && !time_depths && !getenv("RTOW_ONE_STREAM")) ? 2u : 1u;
     const uint32_t shards_per_wg = (nq + isect_grid - 1u) / isect_grid;
     // selects the "general scene" kernel instantiations (rectangles and Translate / RotateY wrappers)
-    const bool rects = ctx->ds.n_rects > 0 || ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0;
+    const bool rects = scene_is_general(ctx);
     for (uint32_t sl = 0; sl < n_slices; ++sl) {
         const uint32_t s0 = sl * S;
         const uint32_t sc = std::min(S, spp - s0);
@@ -785,45 +853,13 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             const bool gen = fuse_gen && depth == 0;
             ip.depth = depth;
             ip.q0 = q0, ip.q1 = q1;
-#define RT_LAUNCH_ISECT(G, R, N, T)                                                                                    \
-    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R, N, T>), dim3(isect_grid_g), dim3(RT_BVH_BLOCK), ctx->isect_lds, sg, ctx->ds, \
-                       qi.a, qi.b, qhit, cin, ip, gpd)
-#define RT_LAUNCH_ISECT_G(G, N)                       \
-    do {                                              \
-        if (ctx->general_lds) RT_LAUNCH_ISECT(G, true, N, true); \
-        else RT_LAUNCH_ISECT(G, true, N, false);      \
-    } while (0)
-            // trees that do not fit LDS use the general instantiation (R = true works for sphere-only scenes too)
-            if (use_bvh && !ctx->bvh_in_lds && gen) RT_LAUNCH_ISECT_G(true, false);
-            else if (use_bvh && !ctx->bvh_in_lds) RT_LAUNCH_ISECT_G(false, false);
-            else if (use_bvh && gen && rects) RT_LAUNCH_ISECT_G(true, true);
-            else if (use_bvh && gen) RT_LAUNCH_ISECT(true, false, true, false);
-            else if (use_bvh && rects) RT_LAUNCH_ISECT_G(false, true);
-            else if (use_bvh) RT_LAUNCH_ISECT(false, false, true, false);
-#undef RT_LAUNCH_ISECT_G
-#undef RT_LAUNCH_ISECT
-            else
-                hipLaunchKernelGGL(k_intersect_list, dim3(q1 - q0), dim3(256), list_lds, sg, ctx->ds, qi.a, qi.b, qhit, cin, ip, gpd);
+            const StepBuffers sb{qi, qo, qhit, cin, cout, rad, totals, gpd};
+            launch_intersect(ctx, sg, use_bvh, gen, isect_grid_g, sb, ip);
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth + 1], st));
             // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
             const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u,
                                  (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u, q0};
-            // sphere geometry for the closest hit inside k_shade<GEN> (candidate lists of a sphere-only scene)
-            const uint32_t n_fused = (gen && !rects && gp.lists) ? ctx->ds.n_spheres : 0u;
-            const size_t shade_lds = shade_lds_bytes(ctx->ds.n_prims + ctx->ds.n_media, n_plds, n_fused, !gen && sp.sort);
-#define RT_LAUNCH_SHADE(P, G, R) \
-    hipLaunchKernelGGL((k_shade<P, G, R>), dim3(q1 - q0), dim3(256), shade_lds, sg, ctx->ds, qi, qhit, qo, cin, cout, rad, sp, totals, gpd)
-#define RT_LAUNCH_SHADE_R(P, G)        \
-    do {                               \
-        if (rects) RT_LAUNCH_SHADE(P, G, true); \
-        else RT_LAUNCH_SHADE(P, G, false);      \
-    } while (0)
-            if (perlin_lds && gen) RT_LAUNCH_SHADE_R(true, true);
-            else if (perlin_lds) RT_LAUNCH_SHADE_R(true, false);
-            else if (gen) RT_LAUNCH_SHADE_R(false, true);
-            else RT_LAUNCH_SHADE_R(false, false);
-#undef RT_LAUNCH_SHADE_R
-#undef RT_LAUNCH_SHADE
+            launch_shade(ctx, sg, gen, !rects && gp.lists != nullptr, q1 - q0, sb, sp);
             n_trace_launches += 2;
         }
         if (n_groups > 1u) {
@@ -942,6 +978,93 @@ int rt_get_depth_timings(RtCtx* ctx, uint32_t max_n, float* isect_ms, float* sha
     return n;
 }
 
+// rt_debug_bounce with RT_FLAG_PRODUCTION_KERNELS: the rays go through the queue and the kernels rt_render launches for a
+// depth >= 1 (the scene's k_intersect instantiation, then the class-sorting k_shade), and the per-ray outcome is read
+// back from the queues: hit records by queue position, radiance slots of the finished paths, survivors by slot.
+static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
+    const uint32_t n = io->n;
+    hipStream_t st = ctx->stream;
+    const QueueGeom qg = queue_geom(ctx, n);
+    const uint32_t nq = qg.nq, cap = qg.cap;
+    int rc;
+    const size_t qbytes = (size_t)nq * cap * sizeof(float4);
+    for (int k = 0; k < 6; ++k)
+        if ((rc = ensure(ctx, ctx->qbuf[k], k % 3 == 2 ? qbytes / 2 : qbytes))) return rc;
+    if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
+    if ((rc = ensure(ctx, ctx->rad, (size_t)n * sizeof(float4)))) return rc;
+    if ((rc = ensure(ctx, ctx->counts, (size_t)2 * nq * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->totals, 4 * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->genp, sizeof(GenParams)))) return rc;
+    if ((rc = ensure(ctx, ctx->dbg, (size_t)n * 6 * sizeof(float)))) return rc;
+    Queue Q[2] = {Queue{(float4*)ctx->qbuf[0].p, (float4*)ctx->qbuf[1].p, (float2*)ctx->qbuf[2].p},
+                  Queue{(float4*)ctx->qbuf[3].p, (float4*)ctx->qbuf[4].p, (float2*)ctx->qbuf[5].p}};
+    uint32_t* counts = (uint32_t*)ctx->counts.p;
+    float* d_o = (float*)ctx->dbg.p;
+    float* d_d = d_o + 3 * (size_t)n;
+    RT_HIP(ctx, hipMemcpyAsync(d_o, io->in_o, 3 * (size_t)n * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(ctx, hipMemcpyAsync(d_d, io->in_d, 3 * (size_t)n * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)2 * nq * sizeof(uint32_t), st));
+    RT_HIP(ctx, hipMemsetAsync(ctx->totals.p, 0, 4 * sizeof(unsigned long long), st));
+    RT_HIP(ctx, hipMemsetAsync(ctx->rad.p, 0xFF, (size_t)n * sizeof(float4), st)); // NaN pattern: a survivor has no slot
+    // one "image row" of n pixels, one sample: slot i is pixel i, so its key is path_key(seed 0, pix i, sample 0)
+    GenParams gp{};
+    gp.nx = n, gp.ny = 1, gp.npix = n, gp.n_rays = n, gp.s0 = 0;
+    gp.shard_band = 1, gp.shard_count = 1, gp.shard_id = 0;
+    gp.nq = nq, gp.cap = cap;
+    gp.inv_npix = gp.inv_nx = (float)((1.0 / (double)n) * (1.0 - 1.0 / 4194304.0));
+    gp.inv_band = (float)(1.0 - 1.0 / 4194304.0);
+    hipLaunchKernelGGL(k_init_counts, dim3((nq + 255u) / 256u), dim3(256), 0, st, gp, counts, (GenParams*)ctx->genp.p);
+    hipLaunchKernelGGL(k_debug_fill, dim3((n + 255u) / 256u), dim3(256), 0, st, gp, Q[0], d_o, d_d);
+    const bool use_bvh = ctx->use_bvh && !(io->flags & RT_FLAG_BRUTE_FORCE);
+    const StepBuffers sb{Q[0], Q[1], (float2*)ctx->qhit.p, counts, counts + nq, (float4*)ctx->rad.p,
+                         (unsigned long long*)ctx->totals.p, (const GenParams*)ctx->genp.p};
+    const IntersectParams ip{nq, cap, (int)io->depth, 0u, nq};
+    launch_intersect(ctx, st, use_bvh, false, qg.isect_grid, sb, ip);
+    const ShadeParams sp{nq, cap, (int)io->depth, 0x7FFFFFFF, 1u, 0u, 0u};
+    launch_shade(ctx, st, false, false, nq, sb, sp);
+    RT_HIP(ctx, hipGetLastError());
+    std::vector<float4> ha((size_t)nq * cap), hb((size_t)nq * cap), hrad(n);
+    std::vector<float2> hc((size_t)nq * cap), hh((size_t)nq * cap);
+    std::vector<uint32_t> hcnt((size_t)2 * nq);
+    RT_HIP(ctx, hipMemcpyAsync(hh.data(), ctx->qhit.p, hh.size() * sizeof(float2), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(ha.data(), Q[1].a, ha.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(hb.data(), Q[1].b, hb.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(hc.data(), Q[1].c, hc.size() * sizeof(float2), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(hrad.data(), ctx->rad.p, hrad.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(hcnt.data(), counts, hcnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipStreamSynchronize(st));
+    auto bits = [](float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        return u;
+    };
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t chunk = i >> 8;
+        const size_t pos = (size_t)(chunk % nq) * cap + (size_t)(chunk / nq) * 256u + (i & 255u);
+        const int hit = (int)bits(hh[pos].y);
+        io->out_hit[i] = hit;
+        io->out_t[i] = hit >= 0 ? hh[pos].x : 0.0f;
+        io->out_alive[i] = 0;
+        for (int k = 0; k < 3; ++k) io->out_attenuation[3 * (size_t)i + k] = io->out_o[3 * (size_t)i + k] = io->out_d[3 * (size_t)i + k] = 0.0f;
+        io->out_radiance[3 * (size_t)i] = hrad[i].x, io->out_radiance[3 * (size_t)i + 1] = hrad[i].y, io->out_radiance[3 * (size_t)i + 2] = hrad[i].z;
+    }
+    size_t n_out = 0;
+    for (uint32_t q = 0; q < nq; ++q) {
+        if (hcnt[nq + q] > cap) return fail(ctx, RT_ERR_DEVICE, "rt_debug_bounce: shard overflow");
+        for (uint32_t k = 0; k < hcnt[nq + q]; ++k, ++n_out) {
+            const size_t pos = (size_t)q * cap + k;
+            const uint32_t slot = bits(ha[pos].w);
+            if (slot >= n || io->out_alive[slot]) return fail(ctx, RT_ERR_DEVICE, "rt_debug_bounce: bad or repeated slot in the output queue");
+            io->out_alive[slot] = 1;
+            io->out_o[3 * (size_t)slot] = ha[pos].x, io->out_o[3 * (size_t)slot + 1] = ha[pos].y, io->out_o[3 * (size_t)slot + 2] = ha[pos].z;
+            io->out_d[3 * (size_t)slot] = hb[pos].x, io->out_d[3 * (size_t)slot + 1] = hb[pos].y, io->out_d[3 * (size_t)slot + 2] = hb[pos].z;
+            io->out_attenuation[3 * (size_t)slot] = hb[pos].w, io->out_attenuation[3 * (size_t)slot + 1] = hc[pos].x, io->out_attenuation[3 * (size_t)slot + 2] = hc[pos].y;
+            for (int c = 0; c < 3; ++c) io->out_radiance[3 * (size_t)slot + c] = 0.0f; // emitted = 0 on every scattering material
+        }
+    }
+    return RT_OK;
+}
+
 int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
     if (!ctx) return RT_ERR_INVALID;
     if (!ctx->has_scene) return fail(ctx, RT_ERR_STATE, "rt_debug_bounce: no scene uploaded");
@@ -950,6 +1073,7 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
         return fail(ctx, RT_ERR_INVALID, "rt_debug_bounce: NULL array");
     if (io->n == 0) return RT_OK;
     RT_HIP(ctx, hipSetDevice(ctx->device));
+    if (io->flags & RT_FLAG_PRODUCTION_KERNELS) return debug_bounce_production(ctx, io);
     const size_t n = io->n;
     // layout of the scratch buffer (floats unless noted)
     const size_t off_o = 0, off_d = off_o + 3 * n, off_key = off_d + 3 * n, off_hit = off_key + 2 * n, off_t = off_hit + n,

@@ -1170,6 +1170,19 @@ __global__ __launch_bounds__(256) void k_accum_counts(const uint32_t* __restrict
     if (threadIdx.x == 0) totals[d] += part[0] + part[1] + part[2] + part[3];
 }
 
+// Test hook (rt_debug_bounce, RT_FLAG_PRODUCTION_KERNELS): caller-given rays into the queue, in the shard lattice of
+// the primary rays, T = 1, slot = ray index.  The production k_intersect / k_shade then run on them.
+__global__ __launch_bounds__(256) void k_debug_fill(GenParams gp, Queue q, const float* __restrict__ in_o,
+                                                    const float* __restrict__ in_d) {
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= gp.n_rays) return;
+    const uint32_t chunk = idx >> 8;
+    const size_t pos = (size_t)(chunk % gp.nq) * gp.cap + (size_t)(chunk / gp.nq) * 256u + (idx & 255u);
+    q.a[pos] = make_float4(in_o[3 * idx], in_o[3 * idx + 1], in_o[3 * idx + 2], __uint_as_float(idx));
+    q.b[pos] = make_float4(in_d[3 * idx], in_d[3 * idx + 1], in_d[3 * idx + 2], 1.0f);
+    q.c[pos] = make_float2(1.0f, 1.0f);
+}
+
 // Test hook: one bounce for caller-given rays, no queues (rt_debug_bounce).
 template <int BLOCK, bool USE_BVH, bool LDS_NODES>
 __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n, int depth, const float* __restrict__ in_o,

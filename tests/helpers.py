@@ -29,3 +29,25 @@ def rays_on_scene(n, seed, center=(0.0, 0.5, 0.0), radius=12.0):
     d = (d * (np.float32(1.0) / ln)[:, None]).astype(np.float32)
     keys = rng.integers(0, 2**32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
     return o, d, keys
+
+
+def fmix32(h):
+    """murmur3 finaliser on uint32 arrays (DESIGN.md "RNG"), written here a third time, in numpy."""
+    h = np.asarray(h, dtype=np.uint64) & 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def path_keys(seed, pix, samp):
+    """(k0, k1) of path (pixel, sample) as uint32 [n, 2] — the key the renderer derives for a slot."""
+    pix = np.asarray(pix, dtype=np.uint64)
+    samp = np.asarray(samp, dtype=np.uint64)
+    s_lo, s_hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    a = fmix32(pix ^ s_lo)
+    k0 = fmix32((a + samp * 0x9E3779B9 + s_hi) & 0xFFFFFFFF)
+    k1 = fmix32(((a ^ 0xA511E9B3) + samp * 0xC2B2AE3D) & 0xFFFFFFFF)
+    return np.stack([k0, k1], axis=1).astype(np.uint32)

@@ -11,7 +11,7 @@ whose product chain is associated differently from the wavefront's T *= a.
 import numpy as np
 import pytest
 
-from helpers import display, rays_on_scene, rmse_display
+from helpers import display, path_keys, rays_on_scene, rmse_display
 
 pytestmark = pytest.mark.gpu
 
@@ -41,7 +41,29 @@ def _check_bounce(rt, orc, renderer, scene, n=20000, depth=0, seed=1):
         fin = np.isfinite(b)
         assert np.array_equal(np.isfinite(a), fin), k
         assert np.allclose(a[fin], b[fin], rtol=2e-5, atol=1e-6), (k, np.abs(a[fin] - b[fin]).max())
+    _check_production_kernels(rt, orc, renderer, scene, o, d, depth)
     return g
+
+
+def _check_production_kernels(rt, orc, renderer, scene, o, d, depth):
+    """The same rays through the ray queue and the kernels rt_render launches for a depth >= 1 (persistent-lane
+    k_intersect of the scene's instantiation, class-sorting k_shade, wave64 compaction), per ray against the oracle.
+    The renderer derives the RNG key from the slot: ray i is pixel i, sample 0, seed 0."""
+    keys = path_keys(0, np.arange(len(o)), np.zeros(len(o), dtype=np.uint64))
+    p = renderer.debug_bounce(o, d, keys, depth=depth, flags=rt._ffi.FLAG_PRODUCTION_KERNELS)
+    c = orc.debug_bounce(scene.flat_ptr, o, d, keys, depth=depth, accel=orc.ACCEL_LIST)
+    assert np.array_equal(p["hit"], c["hit"])
+    assert np.array_equal(p["t"].view(np.uint32), c["t"].view(np.uint32))
+    assert np.array_equal(p["alive"], c["alive"])
+    live = c["alive"].astype(bool)
+    assert np.array_equal(p["o"][live].view(np.uint32), c["o"][live].view(np.uint32))
+    assert np.array_equal(p["d"][live].view(np.uint32), c["d"][live].view(np.uint32))
+    for k, sel in (("attenuation", live), ("radiance", ~live)):  # a finished path keeps no ray, a survivor emits nothing
+        a, b = p[k][sel].astype(np.float64), c[k][sel].astype(np.float64)
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), fin), k
+        assert np.allclose(a[fin], b[fin], rtol=2e-5, atol=1e-6), (k, np.abs(a[fin] - b[fin]).max())
+    assert not p["radiance"][live].any()  # emitted = 0 for everything that scatters (material.rs:12-14)
 
 
 def test_bounce_sphere_scene_all_depth_blocks(rt, orc, renderer):
@@ -217,9 +239,27 @@ def test_render_other_scenes(rt, orc, renderer, name, spp, depth):
     ref, _, so = _oracle(orc, scene, p)
     assert st.n_rays == so.n_rays
     assert st.n_texture_fetches == so.n_texture_fetches
-    fin = np.isfinite(ref) & np.isfinite(img)
-    assert fin.mean() > 0.999
-    assert rmse_display(np.where(fin, img, 0), np.where(fin, ref, 0)) <= (2e-3 if name == "pbr_sweep_scene" else RMSE_TOL)
+    _compare_frames(orc, scene, p, img, ref, name)
+
+
+def _compare_frames(orc, scene, p, img, ref, name):
+    """Frame against the oracle when pixels may be non-finite (pbr.rs: a grazing n_dot_i -> 0 divides by ~0, the
+    attenuation overflows and inf * 0 = NaN poisons the pixel in the reference's arithmetic too).
+    Against the oracle in the wavefront's own product order (EST_ITERATIVE) the non-finite pixels must be THE SAME
+    pixels and the finite ones agree to 2e-5 — RMSE_TOL for a scene with image textures, where a last-ulp difference
+    of acos / atan2 between device and host libm moves a lookup across a texel edge now and then (measured 1.5e-4 on
+    earth_env_scene at 2 spp: isolated pixels); against the reference's recursive order an overflow can strike at a
+    different factor of the chain, so there only the pixels finite in both are compared (RMSE_TOL) and the two masks
+    may differ in a 1e-4 fraction of the pixels at most."""
+    it, _, _ = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_COUNTER, estimator=orc.EST_ITERATIVE))
+    assert np.array_equal(np.isfinite(img), np.isfinite(it)), name
+    fin = np.isfinite(it)
+    e_it = rmse_display(np.where(fin, img, 0), np.where(fin, it, 0))
+    assert e_it <= (RMSE_TOL if scene.flat.n_images else 2e-5), (name, e_it)
+    both = np.isfinite(ref) & np.isfinite(img)
+    assert (np.isfinite(ref) != np.isfinite(img)).mean() <= 1e-4, name
+    e = rmse_display(np.where(both, img, 0), np.where(both, ref, 0))
+    assert e <= RMSE_TOL, (name, e)
 
 
 def test_analytic_images(rt, renderer):
@@ -284,7 +324,7 @@ def test_error_behaviour(rt):
 def test_config4_and_5_full_resolution_low_spp(rt, orc, renderer):
     """BASELINE.json configs 4 (earthmap + newport_loft env sky) and 5 (pbr.rs sweep) at their full
     1920x1080 resolution and 2 spp against the oracle: exact ray and texel-fetch counts, RMSE in tolerance."""
-    for name, depth, tol in (("earth_env_scene", 50, RMSE_TOL), ("pbr_sweep_scene", 50, 2e-3)):
+    for name, depth in (("earth_env_scene", 50), ("pbr_sweep_scene", 50)):
         scene = rt.Scene.build(name, 16 / 9)
         renderer.upload(scene)
         p = rt.make_params(1920, 1080, 2, max_depth=depth)
@@ -292,27 +332,36 @@ def test_config4_and_5_full_resolution_low_spp(rt, orc, renderer):
         ref, _, so = _oracle(orc, scene, p)
         assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth), name
         assert st.n_texture_fetches == so.n_texture_fetches, name
-        fin = np.isfinite(ref) & np.isfinite(img)
-        assert fin.mean() > 0.9999
-        assert rmse_display(np.where(fin, img, 0), np.where(fin, ref, 0)) <= tol, name
+        _compare_frames(orc, scene, p, img, ref, name)
 
 
-def test_config3_resolution_sharded_8_ways(rt, renderer):
-    """BASELINE.json config 3 geometry: 3840x2160 split over 8 row-interleaved shards (rendered one after
-    the other on this GPU) reassembles to the unsharded frame bit for bit; 1 spp keeps it short."""
+def test_config3_full_size_sharded_8_ways(rt, orc, renderer):
+    """BASELINE.json config 3 as stated: sphere_scene 3840x2160, 1024 spp, depth 50 (8 493 465 600 paths, ~21.6 G rays).
+    The unsharded frame and the 8 row-interleaved shards of the 8-GPU run (rendered one after the other on this
+    GPU, reassembled like the gather does) are bit-identical, with equal ray counts per depth; and the same frame
+    at a size the oracle covers (1 spp) matches it: exact rays per depth, RMSE in tolerance."""
     from ray_tracing_in_one_weekend_amd import shard
     scene = rt.Scene.build("sphere_scene", 16 / 9)
     renderer.upload(scene)
-    nx, ny = 3840, 2160
-    full, _, st = renderer.render(scene.camera, rt.make_params(nx, ny, 1, max_depth=50))
-    parts, rays = [], 0
+    nx, ny, spp = 3840, 2160, 1024
+    full, _, st = renderer.render(scene.camera, rt.make_params(nx, ny, spp, max_depth=50, seed=95))
+    assert st.n_paths == 8493465600 and st.n_bad_dir == 0
+    assert np.isfinite(full).all() and 2.4 < st.n_rays / st.n_paths < 2.7
+    parts, rays, per_depth = [], 0, np.zeros(51, dtype=np.int64)
     for r in range(8):
-        im, _, s = renderer.render(scene.camera, rt.make_params(nx, ny, 1, max_depth=50, shard_band=8, shard_count=8, shard_id=r))
+        im, _, s = renderer.render(scene.camera, rt.make_params(nx, ny, spp, max_depth=50, seed=95, shard_band=8, shard_count=8, shard_id=r))
         parts.append(im)
         rays += s.n_rays
+        per_depth += np.array(list(s.rays_per_depth)[:51], dtype=np.int64)
     out = shard.deinterleave(parts, ny, 8, 8)
     assert np.array_equal(out.view(np.uint32), full.view(np.uint32)) and rays == st.n_rays
-    assert st.n_paths == nx * ny
+    assert list(per_depth) == list(st.rays_per_depth)[:51]
+    # the oracle on the same 4K frame, 1 spp (8.3 M paths)
+    p1 = rt.make_params(nx, ny, 1, max_depth=50, seed=95)
+    img, _, s1 = renderer.render(scene.camera, p1)
+    ref, _, so = _oracle(orc, scene, p1)
+    assert s1.n_rays == so.n_rays and list(s1.rays_per_depth) == list(so.rays_per_depth)
+    assert rmse_display(img, ref) <= RMSE_TOL
 
 
 def test_scene_too_large_for_the_lds_bvh_uses_the_list_walk(rt, orc, renderer):
