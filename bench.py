@@ -2,23 +2,30 @@
 """bench.py — headline benchmark of the MI355X wavefront path tracer.
 
 Metric (BASELINE.json): Mray/s (primary + secondary) on demo_scene.rs `sphere_scene`
-("random-spheres", 533 spheres) at 1920x1080, 256 spp, max depth 50 — config 2.
+("random-spheres", 533 spheres) at 1920x1080, 256 spp, max depth 50 — config 2, the default.
+    --config 3   sphere_scene 3840x2160, 1024 spp            (BASELINE.json configs[2])
+    --config 4   earth_env_scene 1920x1080, 512 spp           (configs[3]: ImageTex + environment sky)
+    --config 5   pbr_sweep_scene 1920x1080, 4096 spp          (configs[4]: pbr.rs sweep)
 
-A "step" is one full render of the frame: every pixel x every sample through the wavefront
-kernels (k_gen_primary -> (max_depth+1) x k_trace_shade -> k_resolve per slice, k_finalize),
-framebuffer resident in HBM.  With N > 1 ranks (one process per GPU, torch.distributed, backend
-nccl == RCCL over xGMI) the image rows are sharded in interleaved bands of 8 rows and each
-step ends with the all_gather of the band buffers.  Scaling is WEAK: the per-GPU path count is
-held at config 2's 530,841,600 by rendering spp = 256*N of the same frame, so every rank traces
-(1080/N rows) x 1920 x 256*N samples.
+A "step" is one full render of the frame: every pixel x every sample through the wavefront kernels
+(k_primary_lists, then per depth k_intersect -> k_shade, k_resolve per slice, k_finalize), framebuffer resident in
+HBM.  With N > 1 ranks (one process per GPU, torch.distributed, backend nccl == RCCL over xGMI) the image rows are
+sharded in interleaved bands of 8 rows and each step ends with the all_gather of the band buffers.
+    --scaling weak    (default for config 2) per-GPU work fixed: every rank renders (ny/N rows) x nx x spp*N samples
+    --scaling strong  (default for configs 3-5) the stated frame split over the N ranks
+
+`python bench.py --gpus N` without a torchrun environment starts the N rank processes itself (a child
+`python -m torch.distributed.run` started BEFORE this process touches a GPU) and relays rank 0's JSON line.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) including
-  "roofline":     k_trace_shade algorithmic HBM bytes / its device time (HIP events on its stream)
+  "roofline":     trace-step algorithmic HBM bytes / its device time (HIP events on the launch stream)
   "cpu_baseline": the CPU oracle in reference (stream) order, all host cores, bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,21 +35,37 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
+CONFIGS = {  # BASELINE.json configs[1..4]
+    2: dict(scene="sphere_scene", nx=1920, ny=1080, spp=256, scaling="weak",
+            what="demo_scene.rs sphere_scene (random-spheres, 533 spheres)"),
+    3: dict(scene="sphere_scene", nx=3840, ny=2160, spp=1024, scaling="strong",
+            what="demo_scene.rs sphere_scene (random-spheres, 533 spheres)"),
+    4: dict(scene="earth_env_scene", nx=1920, ny=1080, spp=512, scaling="strong",
+            what="earth_env_scene (earthmap.jpg ImageTex spheres, newport_loft.jpg tex_sky_color)"),
+    5: dict(scene="pbr_sweep_scene", nx=1920, ny=1080, spp=4096, scaling="strong",
+            what="pbr_sweep_scene (pbr.rs GGX metal / plastic / clearcoat sweep, 501 spheres)"),
+}
+
+
+def _latest_profile(pattern, workload_key):
+    """Newest profiles/round*/<pattern> whose bench_config.workload is this run's workload."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", pattern))):
+        try:
+            t = json.load(open(p))
+        except (OSError, ValueError):
+            continue
+        if (t.get("bench_config") or {}).get("workload") == workload_key:
+            best = (p, t)
+    return best
+
 
 def pmc_traffic(workload_key):
     """HBM bytes per trace-step launch from the committed PMC pass of this same command
     (scripts/collect_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections).
     bench.py cannot profile itself, so the number comes from profiles/; null when absent or stale."""
-    import glob
-    best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "traffic*.json"))):
-        try:
-            t = json.load(open(p))
-        except (OSError, ValueError):
-            continue
-        cfg = t.get("bench_config") or {}
-        if cfg.get("workload") == workload_key:
-            best = (p, t)
+    best = _latest_profile("traffic*.json", workload_key)
     if not best:
         return None, None
     p, t = best
@@ -51,23 +74,17 @@ def pmc_traffic(workload_key):
 
 def pmc_valu(workload_key):
     """VALU issue fraction / lane utilisation of the trace kernels from the committed PMC pass of this same command
-    (scripts/collect_valu.py); None when absent or for another workload."""
-    import glob
-    best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "valu*.json"))):
-        try:
-            t = json.load(open(p))
-        except (OSError, ValueError):
-            continue
-        if (t.get("bench_config") or {}).get("workload") == workload_key:
-            best = (p, t)
+    (scripts/collect_valu.py) against the MEASURED issue rate of scripts/micro/mul_rate.hip; None when absent."""
+    best = _latest_profile("valu*.json", workload_key)
     if not best:
         return None
     p, t = best
     out = {k: {"issue_frac": round(v["issue_frac"], 4), "lane_util": round(v["lane_util"], 4)} for k, v in t["kernels"].items()}
+    out["peak_wave_insts_per_s"] = t.get("peak_wave_insts_per_s")
     out["source"] = os.path.relpath(p, ROOT)
-    out["note"] = ("the bound that limits this path: VALU issue slots used / available (1024 SIMDs, 4 cycles per wave64 "
-                   "instruction, 2.4 GHz; > 1 = saturated, see the source file's note); lane_util = active lanes per issued instruction")
+    out["note"] = ("companion roofline: SQ_INSTS_VALU / (kernel seconds x measured peak issue rate); the peak is the v_mul_f32 / "
+                   "v_add_f32 rate of scripts/micro/mul_rate.hip at 8 waves per SIMD (2.1 cycles per wave64 instruction on the "
+                   "SIMD-32, profiles/round2/valu_peak.json), so issue_frac <= 1; lane_util = active lanes per issued instruction")
     return out
 
 
@@ -84,7 +101,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(rt, scene, nx, ny, max_depth, budget_s=15.0):
+def cpu_baseline(rt, scene, name, nx, ny, max_depth, budget_s=15.0):
     """Times the oracle (kind "port": C++ restatement of the reference, stream RNG order, BVH,
     one worker per host core like threadpool's default) on a bounded sample of the workload:
     the same frame at reduced spp (Mray/s does not depend on spp)."""
@@ -102,8 +119,26 @@ def cpu_baseline(rt, scene, nx, ny, max_depth, budget_s=15.0):
     _, _, st = orc.render(scene.flat_ptr, scene.camera, p, opts)
     dt = max(time.time() - t0, 1e-6)
     return {"value": round(st.n_rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": f"sphere_scene {nx}x{ny}, {spp} spp, max_depth {max_depth}, {st.n_rays} rays in {dt:.1f} s "
+            "sample": f"{name} {nx}x{ny}, {spp} spp, max_depth {max_depth}, {st.n_rays} rays in {dt:.1f} s "
                       f"(oracle stream mode: per-column xoshiro256++, recursive estimator, BVH)"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """--gpus N without a torchrun environment: start the N rank processes as a child (this process has not touched a
+    GPU and never will; it only relays the child's output and exit code)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -111,14 +146,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nx", type=int, default=1920)
-    ap.add_argument("--ny", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=256, help="samples per pixel PER GPU (weak scaling)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None)
+    ap.add_argument("--nx", type=int, default=0)
+    ap.add_argument("--ny", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (weak scaling: per GPU)")
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--spp-slice", type=int, default=0)
     ap.add_argument("--band", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launcher-check", action="store_true",
+                    help="rendezvous, world-size assertion and one framebuffer gather of a synthetic band buffer; no rendering "
+                         "(the CPU test of the multi-rank launch path: RTOW_DIST_BACKEND=gloo, no GPU needed)")
     args = ap.parse_args()
+
+    n_req = max(args.gpus, 1)
+    if n_req > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(n_req))
 
     import torch
     import torch.distributed as dist
@@ -126,14 +170,36 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1):
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if world != n_req:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(torchrun --nproc-per-node {n_req}, or let `python bench.py --gpus {n_req}` spawn them)")
     # RTOW_DIST_BACKEND=gloo: rehearsal of the multi-process path on a box with fewer GPUs than ranks
     # (ranks share devices, the gather goes through host memory); the real run is nccl == RCCL over xGMI
     backend = os.environ.get("RTOW_DIST_BACKEND", "nccl")
+    gather_name = "RCCL all_gather over xGMI" if backend == "nccl" else f"{backend} all_gather through host memory (rehearsal)"
+
+    if args.launcher_check:
+        from ray_tracing_in_one_weekend_amd import shard
+        if world > 1:
+            dist.init_process_group(backend="gloo" if backend != "nccl" or not torch.cuda.is_available() else "nccl")
+            assert dist.get_world_size() == n_req
+        ny, nx = 64, 16
+        rows = shard.shard_rows(ny, args.band, world, rank)
+        local = torch.zeros((len(rows), nx, 3), dtype=torch.float32)
+        local[:, :, 0] = torch.as_tensor(rows, dtype=torch.float32)[:, None]  # every pixel carries its image row
+        full = shard.gather_framebuffer(local, ny, args.band) if world > 1 else local
+        ok = bool((full[:, 0, 0] == torch.arange(ny, dtype=torch.float32)).all())
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launcher_check": ok, "n_gpus": world, "rccl_ranks": world if backend == "nccl" else 0,
+                              "backend": backend, "gather": gather_name}))
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(device_index)
     if world > 1:
@@ -141,24 +207,29 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == n_req, (dist.get_world_size(), n_req)
 
     import ray_tracing_in_one_weekend_amd as rt
     from ray_tracing_in_one_weekend_amd import shard
 
+    cfg = CONFIGS[args.config]
+    nx, ny = args.nx or cfg["nx"], args.ny or cfg["ny"]
+    spp = args.spp or cfg["spp"]
+    scaling = args.scaling or cfg["scaling"]
     rt.register_default_images()
-    nx, ny = args.nx, args.ny
-    scene = rt.Scene.build("sphere_scene", nx / ny)
+    scene = rt.Scene.build(cfg["scene"], nx / ny)
     renderer = rt.Renderer(device_index)  # raises if librtow_mi355x.so is missing
     renderer.upload(scene)
-    spp_total = args.spp * world
+    spp_total = spp * world if scaling == "weak" else spp
     params = rt.make_params(nx, ny, spp_total, max_depth=args.max_depth, seed=95, shard_band=args.band,
                             shard_count=world, shard_id=rank, spp_slice=args.spp_slice)
     rows = renderer.shard_rows(params)
-    local = torch.zeros((rows, nx, 3), dtype=torch.float32, device="cuda")
     # a dedicated non-default stream: the library's launches, its HIP events and the RCCL gather are
-    # all ordered on it (stream handle 0 would make the library fall back to its own stream)
+    # all ordered on it (stream handle 0 would make the library fall back to its own stream); the band
+    # buffer is allocated on that stream too
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
+    local = torch.zeros((rows, nx, 3), dtype=torch.float32, device="cuda")
     stream = tstream.cuda_stream
 
     def step(want_stats):
@@ -213,27 +284,29 @@ def main():
         trace_bytes = sum(s.bytes_trace_algorithmic for s in stats)
         launches = sum(s.n_trace_launches for s in stats)
         achieved = trace_bytes / max(trace_s, 1e-12) / 1e9
-        workload = (f"demo_scene.rs sphere_scene (random-spheres, 533 spheres) {nx}x{ny}, "
-                    f"{args.spp} spp per GPU ({spp_total} spp total), max_depth {args.max_depth}, "
+        per_gpu = f"{spp} spp per GPU ({spp_total} spp total)" if scaling == "weak" else f"{spp_total} spp"
+        workload = (f"config {args.config}: {cfg['what']} {nx}x{ny}, {per_gpu}, max_depth {args.max_depth}, "
                     f"seed 95, counter RNG; rows sharded in bands of {args.band} over {world} GPU(s)"
-                    + (", RCCL all_gather of the f32 framebuffer per step" if world > 1 else ""))
+                    + (f", {gather_name} of the f32 framebuffer per step" if world > 1 else ""))
         traffic, traffic_src = pmc_traffic(workload)
         out = {
             "metric": "Mray/s (primary+secondary) at 1920x1080/256spp",
             "value": round(rays_total / elapsed_max / 1e6, 3),
             "unit": "Mray/s",
             "n_gpus": world,
+            "rccl_ranks": world if (backend == "nccl" and world > 1) else 0,  # ranks of the RCCL communicator the gather ran on
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / max(args.steps, 1) * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload,
                        "paths_per_step": int(s0.n_paths) * world, "rays_per_step_rank0": int(s0.n_rays),
                        "rays_per_path": round(s0.n_rays / max(s0.n_paths, 1), 4),
+                       "texture_fetches_per_step_rank0": int(s0.n_texture_fetches),
                        "spp_slices": int(s0.n_slices)},
             "roofline": {"kernel": "trace step = k_intersect + k_shade (the survey's k_trace_shade, split)", "bound": "hbm",
                          "achieved": round(achieved, 2),
@@ -243,16 +316,16 @@ def main():
                          "bytes_per_launch": round(trace_bytes / max(launches, 1), 1),
                          "avg_launch_us": round(trace_s / max(launches, 1) * 1e6, 3),
                          "launches": launches,
-                         "note": "per launch = per kernel launch of the step (2 per depth); algorithmic bytes = 48 B/ray read + "
-                                 "48 B/surviving ray written + 12 B/path radiance (SURVEY.md 8(d): 96 B/ray + 24 B/path over "
-                                 "gen+trace+resolve); time = HIP events around the trace launches of every slice on the launch "
-                                 "stream; traffic = PMC FETCH_SIZE*2 + WRITE_SIZE of both kernels per launch"},
+                         "note": "per launch = per kernel launch of the step (2 per depth and shard group); algorithmic bytes = "
+                                 "48 B/ray read + 48 B/surviving ray written + 12 B/path radiance + 12 B/ImageTex fetch (SURVEY.md 8(d): "
+                                 "96 B/ray + 24 B/path + 12 B/fetch over gen+trace+resolve); time = HIP events around the trace launches "
+                                 "of every slice on the launch stream; traffic = PMC FETCH_SIZE*2 + WRITE_SIZE of both kernels per launch"},
             "whole_path": {"bytes_algorithmic_per_step": int(s0.bytes_algorithmic),
                            "device_seconds_per_step": round(s0.seconds_device, 6),
                            "hbm_frac": round(s0.bytes_algorithmic / max(s0.seconds_device, 1e-12) / 1e9 / HBM_PEAK_GBPS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rt, scene, nx, ny, args.max_depth)
+            out["cpu_baseline"] = cpu_baseline(rt, scene, cfg["scene"], nx, ny, args.max_depth)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 2)
         print(json.dumps(out))
     if world > 1:

@@ -17,8 +17,9 @@
  *   - every function returns 0 on success, a negative RT_ERR_* otherwise; text via
  *     rt_last_error().
  *   - the caller owns all buffers; rt_scene_upload() copies and retains nothing host-side.
- *   - a context is bound to ONE GPU and is driven by one host thread (one process per
- *     GPU; multi-GPU sharding is expressed through RtParams.shard_*).
+ *   - a context (RtCtx) is bound to ONE GPU and is driven by one host thread; multi-GPU sharding is
+ *     expressed through RtParams.shard_* (one process per GPU, the host gathers — bench.py does it with
+ *     torch.distributed) or handled inside the library by an RtMulti (one process, n GPUs, RCCL gather).
  *   - fp32 throughout; image row 0 is the BOTTOM row in the f32 output (reference `j`
  *     order, main.rs:84) and the TOP row in the RGB8 output (after the flip, main.rs:127).
  */
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5u
+#define RT_ABI_VERSION 6u
 
 /* error codes */
 #define RT_OK 0
@@ -242,7 +243,7 @@ typedef struct RtStats {
     double seconds_trace;      /* sum of trace+shade kernel time (HIP events, device clock)   */
     double seconds_device;     /* all kernels of the call (HIP events)                       */
     uint64_t bytes_algorithmic;/* 96*n_rays + 24*n_paths (+12*n_texture_fetches), SURVEY §8(d) */
-    uint64_t bytes_trace_algorithmic; /* trace kernel share: 48*n_rays + 48*n_secondary + 12*n_paths */
+    uint64_t bytes_trace_algorithmic; /* trace kernel share: 48*n_rays + 48*n_secondary + 12*n_paths + 12*n_texture_fetches */
     uint32_t n_trace_launches;
     uint32_t n_slices;
     uint64_t rays_per_depth[64]; /* rays traced at depth d (d < 64) */
@@ -307,6 +308,33 @@ int rt_set_progress(RtCtx* ctx, RtProgressFn fn, void* user);
  * in that slice.
  * Returns the number of depths written (<= max_n), or a negative RT_ERR_*. */
 int rt_get_depth_timings(RtCtx* ctx, uint32_t max_n, float* isect_ms, float* shade_ms, uint64_t* rays);
+
+/* -- multi-GPU: one process, the GPUs of one node, the framebuffer gather inside the library ---------------------
+ * SURVEY.md 8(b)/(e).  The reference's only parallelism is the per-column fan-out over a thread pool with the
+ * world shared read-only (main.rs:72-108); here the scene is replicated on every device, device r renders the image
+ * rows of the row-interleaved bands (j / band) % n == r (RNG keyed by pixel and sample: the frame does not depend on
+ * n), ONE ncclAllGather over RCCL/xGMI brings the equal-sized band buffers together and the first device restores
+ * row order.  librccl is opened at rt_multi_create (dlopen); the single-GPU entry points do not depend on it. */
+typedef struct RtMulti RtMulti;
+/* One RtCtx per listed HIP device + ncclCommInitAll over them.  Replaces main.rs:72-73 for a node. */
+int rt_multi_create(const int* device_ids, int n_devices, RtMulti** out);
+void rt_multi_destroy(RtMulti* m);
+int rt_multi_device_count(const RtMulti* m);
+/* Last error text of `m` (or of the calling thread's last failed rt_multi_create if NULL). */
+const char* rt_multi_last_error(const RtMulti* m);
+/* rt_scene_upload on every device. */
+int rt_multi_scene_upload(RtMulti* m, const RtFlatScene* scene);
+/* Renders the WHOLE frame of `params` (nx x ny, spp; shard_count / shard_id are ignored, shard_band = rows per band,
+ * 0 = 8) split over the devices and gathers it: out_rgb_f32 [ny*nx*3] row 0 = bottom, out_rgb8 [ny*nx*3] flipped,
+ * either may be NULL.  `stats` sums the counters of the devices and takes the maximum of their times. */
+int rt_multi_render(RtMulti* m, const RtCamera* cam, const RtParams* params, float* out_rgb_f32, uint8_t* out_rgb8,
+                    RtStats* stats);
+/* The de-interleave step on its own: `d_gathered` is a DEVICE buffer of n_shards band buffers, each
+ * max_r rt_shard_rows(ny, band, n_shards, r) rows of nx*3 floats (what the all_gather delivers); writes the frame in
+ * image row order to d_out_rgb_f32 [ny*nx*3] and / or the quantised, flipped image to d_out_rgb8 (device pointers,
+ * either may be NULL).  `stream` as in rt_render_device. */
+int rt_deinterleave_bands(RtCtx* ctx, const void* d_gathered, uint32_t nx, uint32_t ny, uint32_t band, uint32_t n_shards,
+                          void* d_out_rgb_f32, void* d_out_rgb8, void* stream);
 
 /* -- single-bounce evaluation (test hook) --------------------------------------------------
  * Runs ONE closest-hit + shade step (main.rs:44-58 for one depth) over `n` caller-given

@@ -96,9 +96,11 @@ class RtBounceIO(C.Structure):
 # void (*RtProgressFn)(void* user, uint32_t spp_done, uint32_t spp_total, const uint8_t* rgb8, uint32_t nx, uint32_t rows)
 RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32)
 
+EXPECTED_ABI = 6  # RT_ABI_VERSION the struct layouts and prototypes below were written for
 GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
                "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce",
-               "rt_get_depth_timings", "rt_set_progress"]
+               "rt_get_depth_timings", "rt_set_progress", "rt_multi_create", "rt_multi_destroy", "rt_multi_device_count",
+               "rt_multi_last_error", "rt_multi_scene_upload", "rt_multi_render", "rt_deinterleave_bands"]
 HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
                 "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
                 "rth_sphere", "rth_rect", "rth_gbox", "rth_translate", "rth_rotate_y", "rth_constant_medium", "rth_hitable_bbox", "rth_set_sky", "rth_set_camera", "rth_scene_finish", "rth_scene_flat",
@@ -124,6 +126,9 @@ def load_gpu_library():
     lib = C.CDLL(GPU_LIB_PATH)
     vp = C.c_void_p
     lib.rt_abi_version.restype = C.c_uint32
+    if lib.rt_abi_version() != EXPECTED_ABI:  # a stale .so would be read with the wrong struct layouts
+        raise GpuLibraryMissing(f"{GPU_LIB_PATH} has ABI version {lib.rt_abi_version()}, this package expects {EXPECTED_ABI}: "
+                                "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     lib.rt_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.rt_ctx_create.restype = C.c_int
     lib.rt_ctx_destroy.argtypes = [vp]
@@ -146,6 +151,20 @@ def load_gpu_library():
     lib.rt_debug_bounce.restype = C.c_int
     lib.rt_set_progress.argtypes = [vp, RtProgressFn, vp]
     lib.rt_set_progress.restype = C.c_int
+    lib.rt_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.rt_multi_create.restype = C.c_int
+    lib.rt_multi_destroy.argtypes = [vp]
+    lib.rt_multi_destroy.restype = None
+    lib.rt_multi_device_count.argtypes = [vp]
+    lib.rt_multi_device_count.restype = C.c_int
+    lib.rt_multi_last_error.argtypes = [vp]
+    lib.rt_multi_last_error.restype = C.c_char_p
+    lib.rt_multi_scene_upload.argtypes = [vp, C.POINTER(RtFlatScene)]
+    lib.rt_multi_scene_upload.restype = C.c_int
+    lib.rt_multi_render.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), _f, _u8, C.POINTER(RtStats)]
+    lib.rt_multi_render.restype = C.c_int
+    lib.rt_deinterleave_bands.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+    lib.rt_deinterleave_bands.restype = C.c_int
     _gpu_lib = lib
     return lib
 

@@ -280,6 +280,14 @@ class Renderer:
             self._raise("rt_debug_bounce", rc)
         return out
 
+    def deinterleave_bands(self, d_gathered, nx, ny, band, n_shards, d_out_f32=None, d_out_u8=None, stream=None):
+        """rt_deinterleave_bands on device pointers (ints): gathered band buffers -> frame in image row order."""
+        rc = self._lib.rt_deinterleave_bands(self._ctx, C.c_void_p(d_gathered), nx, ny, band, n_shards,
+                                             C.c_void_p(d_out_f32) if d_out_f32 else None, C.c_void_p(d_out_u8) if d_out_u8 else None,
+                                             C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            self._raise("rt_deinterleave_bands", rc)
+
     def close(self):
         if self._ctx:
             self._lib.rt_ctx_destroy(self._ctx)
@@ -311,3 +319,51 @@ def output_file_name(unix_seconds=-1):
     if lib.rth_output_file_name(int(unix_seconds), buf, 64) != 0:
         raise RtError("rth_output_file_name failed")
     return buf.value.decode()
+
+
+class MultiRenderer:
+    """The GPUs of one node behind one handle (rt_multi_create): every device renders its row-interleaved bands, RCCL
+    gathers the frame inside the library.  Replaces the thread-pool fan-out of main.rs:72-108 for a node."""
+
+    def __init__(self, devices):
+        self._lib = _ffi.load_gpu_library()
+        self._m = C.c_void_p()
+        ids = (C.c_int * len(devices))(*devices)
+        rc = self._lib.rt_multi_create(ids, len(devices), C.byref(self._m))
+        if rc != 0:
+            raise RtError(f"rt_multi_create({list(devices)}) failed ({rc}): {self._lib.rt_multi_last_error(None).decode()}")
+
+    def _raise(self, what, rc):
+        raise RtError(f"{what} failed ({rc}): {self._lib.rt_multi_last_error(self._m).decode()}")
+
+    @property
+    def n_devices(self):
+        return self._lib.rt_multi_device_count(self._m)
+
+    def upload(self, scene):
+        ptr = scene.flat_ptr if isinstance(scene, Scene) else C.pointer(scene)
+        rc = self._lib.rt_multi_scene_upload(self._m, ptr)
+        if rc != 0:
+            self._raise("rt_multi_scene_upload", rc)
+
+    def render(self, camera, params, want_rgb8=False):
+        """Returns (f32 image [ny, nx, 3] (row 0 = bottom), rgb8 or None, RtStats summed over the devices)."""
+        img = np.zeros((params.ny, params.nx, 3), dtype=np.float32)
+        rgb8 = np.zeros((params.ny, params.nx, 3), dtype=np.uint8) if want_rgb8 else None
+        st = RtStats()
+        rc = self._lib.rt_multi_render(self._m, C.byref(camera), C.byref(params), img.ctypes.data_as(C.POINTER(C.c_float)),
+                                       rgb8.ctypes.data_as(C.POINTER(C.c_uint8)) if want_rgb8 else None, C.byref(st))
+        if rc != 0:
+            self._raise("rt_multi_render", rc)
+        return img, rgb8, st
+
+    def close(self):
+        if self._m:
+            self._lib.rt_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -32,7 +32,7 @@ def _run(cmd):
 def build_gpu_library(force=False):
     """hipcc --offload-arch=gfx950: HIP kernels + C-ABI -> librtow_mi355x.so"""
     csrc = os.path.join(PKG_DIR, "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("rt_api.hip", "rt_kernels.h", "rt_device.h", "rt_bvh.h")]
+    srcs = [os.path.join(csrc, f) for f in ("rt_api.hip", "rt_kernels.h", "rt_device.h", "rt_bvh.h", "rt_multi.h")]
     srcs.append(os.path.join(ROOT, "include", "rtow_mi355x.h"))
     out = os.path.join(PKG_DIR, "librtow_mi355x.so")
     if force or _newer(out, srcs):

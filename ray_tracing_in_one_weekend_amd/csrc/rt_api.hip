@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -333,9 +334,19 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: perlin tables missing");
     if (s->n_images && (!s->img_w || !s->img_h || !s->img_offset || !s->texels))
         return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: image arrays missing");
-    for (uint32_t i = 0; i < s->n_spheres; ++i)
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
         if (s->sph_mat[i] >= s->n_materials)
             return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: sphere " + std::to_string(i) + " has material index out of range");
+        // non-finite geometry would reach the tree builder's sort comparators and bin casts (host-side UB)
+        if (!std::isfinite(s->sph_cx[i]) || !std::isfinite(s->sph_cy[i]) || !std::isfinite(s->sph_cz[i]) || !std::isfinite(s->sph_r[i]))
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: sphere " + std::to_string(i) + " has a centre or radius that is not finite");
+    }
+    for (uint32_t i = 0; i < 3u * s->n_rects && s->rect_min && s->rect_max; ++i)
+        if (!std::isfinite(s->rect_min[i]) || !std::isfinite(s->rect_max[i]))
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: rectangle " + std::to_string(i / 3u) + " has a bound that is not finite");
+    for (uint32_t i = 0; i < 4u * s->n_xforms && s->xf_param; ++i)
+        if (!std::isfinite(s->xf_param[i]))
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: transform " + std::to_string(i / 4u) + " has a parameter that is not finite");
     if (s->n_xforms && (!s->xf_type || !s->xf_param || !s->xf_parent))
         return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: transform arrays missing");
     for (uint32_t i = 0; i < s->n_xforms; ++i) {
@@ -916,7 +927,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         stats->seconds_trace = trace_ms * 1e-3;
         stats->seconds_device = ms * 1e-3;
         stats->bytes_algorithmic = 96ull * stats->n_rays + 24ull * stats->n_paths + 12ull * stats->n_texture_fetches;
-        stats->bytes_trace_algorithmic = 48ull * stats->n_rays + 48ull * stats->n_rays_secondary + 12ull * stats->n_paths;
+        stats->bytes_trace_algorithmic = 48ull * stats->n_rays + 48ull * stats->n_rays_secondary + 12ull * stats->n_paths +
+                                         12ull * stats->n_texture_fetches;
         stats->n_trace_launches = n_trace_launches;
         stats->n_slices = n_slices;
         stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
@@ -1117,3 +1129,5 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
 }
 
 } // extern "C"
+
+#include "rt_multi.h"

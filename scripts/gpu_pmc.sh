@@ -5,6 +5,7 @@ export TMPDIR=/tmp
 out=${1:-gpurun_out/pmc}; shift
 args=${@:---steps 1 --warmup 0 --no-cpu-baseline --spp 32}
 mkdir -p $out
+py=$(python -c 'import sys; print(sys.executable)')  # the interpreter binary itself: no PATH shim behind rocprofv3's `--`
 i=0
 for grp in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" \
@@ -14,6 +15,6 @@ for grp in \
   "TCC_HIT_sum TCC_MISS_sum" \
   "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/g$i -- python bench.py $args > $out/g$i.log 2>&1
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/g$i -- $py bench.py $args > $out/g$i.log 2>&1
   echo "group $i ($grp) exit $?"
 done

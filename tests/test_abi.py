@@ -23,7 +23,7 @@ def test_gpu_library_exports_every_declared_symbol(rt):
     assert set(names) == set(rt._ffi.GPU_SYMBOLS), (names, rt._ffi.GPU_SYMBOLS)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.rt_abi_version() == 5
+    assert lib.rt_abi_version() == 6 == rt._ffi.EXPECTED_ABI
 
 
 def test_host_library_exports_every_declared_symbol(rt):

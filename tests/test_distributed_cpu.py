@@ -70,3 +70,24 @@ def test_deinterleave_roundtrip_uneven_rows():
         buf[:len(rows)] = img[rows]
         parts.append(buf)
     assert np.array_equal(shard.deinterleave(parts, ny, band, world), img)
+
+
+def test_bench_launcher_spawns_the_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun environment must start two rank processes itself (before it touches a
+    GPU), rendezvous on 127.0.0.1, see world size 2 and gather a band buffer.  --launcher-check does exactly that without
+    rendering (no GPU here); gloo stands in for RCCL."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RTOW_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-check", "--band", "5"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["launcher_check"] is True and out["n_gpus"] == 2 and out["backend"] == "gloo"
+    # a rank count that does not match --gpus is refused, not silently benchmarked as something else
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-check"], env=env2,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -321,6 +321,22 @@ def test_error_behaviour(rt):
     r.close()
 
 
+def test_non_finite_geometry_is_rejected(rt):
+    """A NaN / infinite centre, radius, rectangle bound or transform parameter would reach the tree builder's sort
+    comparators (host-side undefined behaviour): rt_scene_upload returns RT_ERR_INVALID instead."""
+    import ctypes as C
+    r = rt.Renderer(0)
+    scene = rt.Scene.build("sphere_scene", 2.0)
+    for field, bad in (("sph_cx", np.nan), ("sph_r", np.inf), ("sph_cz", -np.inf)):
+        fs = rt.RtFlatScene.from_buffer_copy(scene.flat)
+        arr = np.ctypeslib.as_array(getattr(fs, field), shape=(fs.n_spheres,)).astype(np.float32, copy=True)
+        arr[7] = bad
+        setattr(fs, field, arr.ctypes.data_as(C.POINTER(C.c_float)))
+        with pytest.raises(rt.RtError, match="finite"):
+            r.upload(fs)
+    r.close()
+
+
 def test_config4_and_5_full_resolution_low_spp(rt, orc, renderer):
     """BASELINE.json configs 4 (earthmap + newport_loft env sky) and 5 (pbr.rs sweep) at their full
     1920x1080 resolution and 2 spp against the oracle: exact ray and texel-fetch counts, RMSE in tolerance."""
@@ -362,6 +378,60 @@ def test_config3_full_size_sharded_8_ways(rt, orc, renderer):
     ref, _, so = _oracle(orc, scene, p1)
     assert s1.n_rays == so.n_rays and list(s1.rays_per_depth) == list(so.rays_per_depth)
     assert rmse_display(img, ref) <= RMSE_TOL
+
+
+def test_in_library_multi_gpu_entry_points(rt, renderer):
+    """rt_multi_* (one process, RCCL gather inside the library).  This box has one GPU, so: (1) the one-device
+    RtMulti — ncclCommInitAll, an all_gather over one rank, the de-interleave and the RGB8 quantisation — must
+    reproduce rt_render bit for bit; (2) the assembly of an 8-GPU run goes through the same entry point
+    (rt_deinterleave_bands) on 8 shards rendered one after the other into the layout the all_gather delivers."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself is linked against (device buffers for part 2)
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+
+    def dev_zeros(nbytes):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), nbytes) == 0 and hip.hipMemset(p, 0, nbytes) == 0
+        return p
+
+    def to_host(p, arr):
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemcpy(arr.ctypes.data_as(ctypes.c_void_p), p, arr.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return arr
+
+    scene = rt.Scene.build("sphere_scene", 16 / 9)
+    renderer.upload(scene)
+    nx, ny, band = 320, 181, 8  # 181 rows: the shards differ in size and the band buffers are padded
+    p = rt.make_params(nx, ny, 6, max_depth=20, seed=95)
+    ref, ref8, st = renderer.render(scene.camera, p, want_rgb8=True)
+    m = rt.MultiRenderer([0])
+    assert m.n_devices == 1
+    m.upload(scene)
+    img, rgb8, sm = m.render(scene.camera, p, want_rgb8=True)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and np.array_equal(rgb8, ref8)
+    assert sm.n_rays == st.n_rays and sm.n_paths == st.n_paths and list(sm.rays_per_depth) == list(st.rays_per_depth)
+    with pytest.raises(rt.RtError, match="twice"):
+        rt.MultiRenderer([0, 0])
+    m.close()
+    for world in (8, 3):
+        pad = max(renderer.shard_rows(rt.make_params(nx, ny, 6, shard_band=band, shard_count=world, shard_id=r)) for r in range(world))
+        band_bytes = pad * nx * 3 * 4
+        gathered = dev_zeros(world * band_bytes)
+        rays = 0
+        for r in range(world):
+            ps = rt.make_params(nx, ny, 6, max_depth=20, seed=95, shard_band=band, shard_count=world, shard_id=r)
+            rays += renderer.render_device(scene.camera, ps, gathered.value + r * band_bytes).n_rays
+        out, out8 = dev_zeros(ny * nx * 3 * 4), dev_zeros(ny * nx * 3)
+        renderer.deinterleave_bands(gathered.value, nx, ny, band, world, out.value, out8.value)
+        full = to_host(out, np.zeros((ny, nx, 3), np.float32))
+        full8 = to_host(out8, np.zeros((ny, nx, 3), np.uint8))
+        assert np.array_equal(full.view(np.uint32), ref.view(np.uint32)) and rays == st.n_rays
+        assert np.array_equal(full8, ref8)
+        for b in (gathered, out, out8):
+            assert hip.hipFree(b) == 0
 
 
 def test_scene_too_large_for_the_lds_bvh_uses_the_list_walk(rt, orc, renderer):
@@ -512,6 +582,15 @@ def test_repeated_renders_reuploads_and_contexts(rt):
         if it == 3:
             free_mid = free_bytes()
     assert abs(free_bytes() - free_mid) < (8 << 20)  # steady state: no growth per call
+    # two sphere-only scenes of different size in two contexts (same k_intersect instantiation, 51 KB and ~1 KB of
+    # tree): the dynamic-LDS attribute is per function and process-wide, so the larger context must keep working after
+    # the smaller one has uploaded
+    s3 = rt.Scene.build("test_sphere", 2.0)
+    b.upload(s3)
+    i1, _, _ = a.render(s1.camera, rt.make_params(96, 48, 4, max_depth=10))
+    i3, _, _ = b.render(s3.camera, rt.make_params(96, 48, 4, max_depth=10))
+    i1b, _, _ = a.render(s1.camera, rt.make_params(96, 48, 4, max_depth=10))
+    assert np.array_equal(i1, ref1) and np.array_equal(i1b, ref1) and np.isfinite(i3).all()
     a.close()
     b.close()
     assert free0 - free_bytes() < (64 << 20)  # everything the two contexts allocated is released
