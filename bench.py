@@ -316,7 +316,8 @@ def main():
                          "bytes_per_launch": round(trace_bytes / max(launches, 1), 1),
                          "avg_launch_us": round(trace_s / max(launches, 1) * 1e6, 3),
                          "launches": launches,
-                         "note": "per launch = per kernel launch of the step (2 per depth and shard group); algorithmic bytes = "
+                         "note": "per launch = one kernel of one depth over all shards (2 per depth; each runs as two concurrent half-grid dispatches on two "
+                                 "streams, so rocprof lists twice as many dispatches of about this duration); algorithmic bytes = "
                                  "48 B/ray read + 48 B/surviving ray written + 12 B/path radiance + 12 B/ImageTex fetch (SURVEY.md 8(d): "
                                  "96 B/ray + 24 B/path + 12 B/fetch over gen+trace+resolve); time = HIP events around the trace launches "
                                  "of every slice on the launch stream; traffic = PMC FETCH_SIZE*2 + WRITE_SIZE of both kernels per launch"},

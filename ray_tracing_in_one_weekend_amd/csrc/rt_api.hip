@@ -830,9 +830,11 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     // waits on HBM and leaves the VALUs idle (profiles/round2).  Each half of the shards runs its own chain
     // intersect -> shade -> intersect ... on its own stream; the two chains drift apart because the kernels differ in
     // length, and the dispatcher fills every CU with waves of both kinds.  Same kernels, same results; config 2 runs
-    // 2 % faster than with one chain over all shards (forcing the two chains half a step apart with events, so that one
-    // always intersects while the other shades, was 12 % SLOWER: half-size grids in lockstep).  Per-depth timing
-    // needs the single chain.
+    // 2.2 % faster than with one chain over all shards (68.0 -> 66.5 ms; three, four and eight groups: 83 / 82 / 104 ms;
+    // forcing the two chains half a step apart with events, so that one always intersects while the other shades: 75 ms,
+    // half-size grids in lockstep).  The two half-grid launches of a depth run side by side, so a "launch" in RtStats is
+    // the logical one — one kernel, one depth, all shards — and rocprof shows each half lasting about that long.
+    // Per-depth timing needs the single chain.
     const uint32_t n_groups = (nq >= 2u * RT_ISECT_MAX_SHARDS && !time_depths && !getenv("RTOW_ONE_STREAM")) ? 2u : 1u;
     const uint32_t shards_per_wg = (nq + isect_grid - 1u) / isect_grid;
     // selects the "general scene" kernel instantiations (rectangles and Translate / RotateY wrappers)
@@ -871,7 +873,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u,
                                  (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u, q0};
             launch_shade(ctx, sg, gen, !rects && gp.lists != nullptr, q1 - q0, sb, sp);
-            n_trace_launches += 2;
+            if (grp == 0u) n_trace_launches += 2;
         }
         if (n_groups > 1u) {
             RT_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));

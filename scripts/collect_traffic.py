@@ -52,10 +52,13 @@ for k in KERNELS:
     wb = tot[(k, "WRITE_SIZE")] * 1024.0
     res["kernels"][k] = {"launches": launches[k], "fetch_bytes": fb, "write_bytes": wb}
     total_bytes += fb + wb
-pairs = max(launches["k_shade"], 1)
+# a "launch" is the logical one of bench.py / RtStats: one kernel, one depth, all shards (issued as two concurrent
+# half-grid launches on two streams, so rocprof sees twice as many dispatches)
+n_logical = (bench_line or {}).get("roofline", {}).get("launches") or max(launches["k_shade"], 1)
 res["trace_step_bytes_total"] = total_bytes
-res["trace_step_launch_pairs"] = pairs
-res["trace_step_bytes_per_launch"] = total_bytes / (2 * pairs)
+res["trace_step_dispatches"] = launches["k_shade"] + launches["k_intersect"]
+res["trace_step_launches"] = n_logical
+res["trace_step_bytes_per_launch"] = total_bytes / n_logical
 if bench_line:
     res["bench_config"] = bench_line.get("config")
     res["algorithmic_bytes_per_launch"] = bench_line["roofline"]["bytes_per_launch"]
