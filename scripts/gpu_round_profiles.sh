@@ -1,0 +1,25 @@
+#!/bin/bash
+# The measurements a round commits under profiles/roundN (run on the GPU box): bash scripts/gpu_round_profiles.sh profiles/round2
+# bench lines of configs 2-5, the rocprofv3 kernel statistics of the same commands, PMC traffic and VALU passes of config 2,
+# the per-dispatch PMC table and the VALU issue-rate microbenchmark.
+export TMPDIR=/tmp
+out=${1:-gpurun_out/profiles}; mkdir -p $out
+py=$(python -c 'import sys; print(sys.executable)')
+./scripts/micro/mul_rate $out/valu_peak.json > $out/mul_rate.txt 2>&1
+$py bench.py --steps 20 --warmup 5 > $out/bench_config2.json 2> $out/bench_config2.err
+for c in 3 4 5; do $py bench.py --config $c --steps 3 --warmup 1 > $out/bench_config$c.json 2> $out/bench_config$c.err; done
+for c in 2 4 5; do
+  extra=""; [ $c != 2 ] && extra="--config $c"
+  rm -rf $out/prof_tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_tmp -- $py bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline > $out/kernel_stats_config$c.log 2>&1
+  find $out/prof_tmp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats_config$c.csv
+done
+rm -rf $out/prof_tmp
+$py scripts/collect_traffic.py $out/traffic_config2.json > $out/traffic_config2.log 2>&1
+$py scripts/collect_valu.py $out/valu_config2.json > $out/valu_config2.log 2>&1
+$py scripts/collect_traffic.py $out/traffic_config4.json --config 4 --steps 1 --warmup 0 --no-cpu-baseline > $out/traffic_config4.log 2>&1
+$py scripts/collect_traffic.py $out/traffic_config5.json --config 5 --steps 1 --warmup 0 --no-cpu-baseline > $out/traffic_config5.log 2>&1
+$py scripts/pmc_probe.py $out/pmc_probe_tmp "" 128 > $out/pmc_per_dispatch_config2_128spp.txt 2>&1
+rm -rf $out/pmc_probe_tmp gpurun_out/pmc_*
+$py scripts/gpu_scene_table.py 64 $out/scene_table.json > $out/scene_table.txt 2>&1
+echo done
