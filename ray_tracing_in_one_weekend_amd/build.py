@@ -29,6 +29,17 @@ def _run(cmd):
     return r.stdout
 
 
+def build_gpu_debug_library(out=None):
+    """The same library with -DRT_DEBUG_QUEUE_BOUNDS (device-side traps on a queue position beyond its shard's capacity);
+    select it with RTOW_GPU_LIB=<path> for a test run."""
+    csrc = os.path.join(PKG_DIR, "csrc")
+    out = out or os.path.join(ROOT, "build", "librtow_mi355x_debug.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    _run([hipcc] + HIPCC_FLAGS + ["-DRT_DEBUG_QUEUE_BOUNDS", "-o", out, os.path.join(csrc, "rt_api.hip")])
+    return out
+
+
 def build_gpu_library(force=False):
     """hipcc --offload-arch=gfx950: HIP kernels + C-ABI -> librtow_mi355x.so"""
     csrc = os.path.join(PKG_DIR, "csrc")

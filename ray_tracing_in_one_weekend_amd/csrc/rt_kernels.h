@@ -731,6 +731,9 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) off = (k == t) ? v - pre[t] : off;
                 const uint32_t shard = ip.q0 + blockIdx.x + k * gridDim.x;
                 pos = (size_t)shard * ip.cap + off;
+#ifdef RT_DEBUG_QUEUE_BOUNDS
+                if (off >= ip.cap || shard >= ip.q1) __builtin_trap();
+#endif
                 uint4 list = make_uint4(RT_LIST_OVERFLOW, 0u, 0u, 0u);
                 // sphere-only scene with candidate lists: k_shade<GEN> finds the closest hit of a listed pixel itself;
                 // only the rays of pixels whose list overflowed are traced (and recorded) here
@@ -1096,6 +1099,9 @@ __global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const 
                     const uint32_t rk =
                         __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                     const size_t pos = qbase + wbase + rk;
+#ifdef RT_DEBUG_QUEUE_BOUNDS // debug builds: a shard never receives more rays than it held (capacity `cap`)
+                    if (wbase + rk >= tp.cap) __builtin_trap();
+#endif
                     V3 Tn = T * bo.attenuation;
                     if (tp.russian_roulette) Tn = Tn / rr_threshold; // (T * a) / threshold
                     qout.a[pos] = make_float4(bo.o.x, bo.o.y, bo.o.z, __uint_as_float(slot));
