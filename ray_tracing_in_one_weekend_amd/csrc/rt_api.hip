@@ -744,7 +744,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         }
         S = (uint32_t)std::max<uint64_t>(1, max_rays / npix64);
     }
-    S = std::min(S, spp);
+    S = std::min(std::min(S, spp), 1u << 20); // udiv_inv (slot -> sample, pixel) wants quotients below 2^21
     if ((uint64_t)S * npix64 > 0xFFFFFF00ull) S = (uint32_t)(0xFFFFFF00ull / npix64);
     if (S == 0) return fail(ctx, RT_ERR_UNSUPPORTED, "render: shard has more than 2^32 pixels");
     const uint32_t n_slices = (spp + S - 1) / S;

@@ -51,12 +51,7 @@ struct GenParams {
     float inv_npix, inv_nx, inv_band; // reciprocals rounded towards zero by 2^-22 (udiv_inv)
 };
 
-__device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t band, uint32_t count, uint32_t id) {
-    if (count <= 1) return lj;
-    return ((lj / band) * count + id) * band + (lj % band);
-}
-
-// x / d for the slot arithmetic below (quotients below 2^21): a float product that never exceeds the true quotient
+// x / d for the slot arithmetic of gen_primary / path_key_of_slot (quotients below 2^21): a float product that never exceeds the true quotient
 // (inv = (1/d)(1 - 2^-22) absorbs the roundings of the conversion and of the product) and two correction steps.
 __device__ __forceinline__ uint32_t udiv_inv(uint32_t x, uint32_t d, float inv, uint32_t& rem) {
     uint32_t qt = (uint32_t)((float)x * inv);
@@ -66,6 +61,11 @@ __device__ __forceinline__ uint32_t udiv_inv(uint32_t x, uint32_t d, float inv, 
     rem = r;
     return qt;
 }
+__device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t band, uint32_t count, uint32_t id) {
+    if (count <= 1) return lj;
+    return ((lj / band) * count + id) * band + (lj % band);
+}
+
 // RNG key of the path in slot `slot` of the slice: the inverse of slot = s_local * npix + pixel_local, then path_key
 // exactly as gen_primary computes it.
 __device__ __forceinline__ void path_key_of_slot(const GenParams& gp, uint32_t slot, uint32_t& k0, uint32_t& k1) {
@@ -85,10 +85,9 @@ __device__ __forceinline__ void path_key_of_slot(const GenParams& gp, uint32_t s
 // idx = s_local * npix + pixel_local, so consecutive idx are consecutive pixels of a row.
 __device__ __forceinline__ void gen_primary(const GenParams& gp, uint32_t idx, V3& o, V3& d, uint32_t& k0, uint32_t& k1,
                                             uint32_t& pl) {
-    const uint32_t s_local = idx / gp.npix;
-    pl = idx - s_local * gp.npix; // local pixel
-    const uint32_t lj = pl / gp.nx;
-    const uint32_t i = pl - lj * gp.nx;
+    uint32_t i;
+    const uint32_t s_local = udiv_inv(idx, gp.npix, gp.inv_npix, pl); // pl = local pixel
+    const uint32_t lj = udiv_inv(pl, gp.nx, gp.inv_nx, i);
     const uint32_t j = local_row_to_image_row(lj, gp.shard_band, gp.shard_count, gp.shard_id);
     const uint32_t samp = gp.s0 + s_local;
     Rng rng;
