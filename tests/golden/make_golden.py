@@ -118,6 +118,22 @@ def build_vectors():
     case = {"c": rot_c, "r": SPHERE_R, "mat": dict(type=1, tex=TEX), "rot": (sin_t, cos_t)}
     out["rotate_y"] = {"angle": ang, "sin": bits(sin_t), "cos": bits(cos_t), "c": list(rot_c), "depth": 2,
                        "rays": run_case(case, make_rays(24, 300, world_c, SPHERE_R), 7, 2)}
+    # XZRect below a Translate, Diffuse (hitable.rs:284-322, 404-418): hits from above (front) and from below (back face)
+    rect = {"axis": 1, "min": (-1.0, 0.5, -1.25), "max": (1.5, 0.5, 1.0), "offset": (0.3, 0.2, -0.1)}
+    case = {"rect": rect, "mat": dict(type=1, tex=TEX)}
+    rays = []
+    for i in range(32):  # from above (front face) and, every fourth, from below (back face); a fifth aim beside the rectangle
+        up = -1.0 if i % 4 == 3 else 1.0
+        o = R.v3(0.55 + rng.uniform(-2, 2), 0.7 + up * rng.uniform(1.0, 3.0), -0.225 + rng.uniform(-2, 2))
+        tgt = R.v3(0.3 + rng.uniform(-1.3, 1.8), 0.7, -0.1 + rng.uniform(-1.55, 1.3))
+        rays.append((o, R.normalize(R.sub(tgt, o))))
+    out["rect_translate"] = {"rect": {k: list(v) if isinstance(v, tuple) else v for k, v in rect.items()}, "depth": 1,
+                             "rays": run_case(case, rays, 7, 1)}
+    # ConstantMedium over a sphere, Isotropic phase function (hitable.rs:523-579, material.rs:99-113)
+    density = 1.5
+    nid = R.f32(-1.0) / R.f32(density)  # ConstantMedium::new: -1. / density
+    case = {"c": SPHERE_C, "r": SPHERE_R, "mat": dict(type=5, tex=TEX), "medium": {"neg_inv_density": nid}}
+    out["medium"] = {"density": density, "depth": 3, "rays": run_case(case, make_rays(32, 700, SPHERE_C, SPHERE_R), 7, 3)}
     # Diffuse over a PerlinTex with a fixed table (texture.rs:93-146, 164-168)
     vec = (rng.uniform(-1, 1, size=(256, 3))).astype(np.float32)
     perm = np.stack([rng.permutation(256) for _ in range(3)]).astype(np.uint16)

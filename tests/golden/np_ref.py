@@ -176,6 +176,57 @@ def rotate_y_sphere_hit(sin_t, cos_t, c, r, o, d, t_min, t_max):
     return h
 
 
+def rect_hit(axis, mn, mx, o, d, t_min, t_max):
+    """XYRect / XZRect / YZRect::hit (hitable.rs:251-270, 291-310, 331-350): axis = the constant coordinate (0 x, 1 y, 2 z),
+    the plane is min[axis]; uv = ((p - min) / (max - min)) over the two other axes; outward normal = +axis."""
+    t = (mn[axis] - o[axis]) / d[axis]
+    if t < t_min or t > t_max:
+        return None
+    p = add(o, scale(d, t))
+    ua, va = ((1, 2), (0, 2), (0, 1))[axis]
+    if p[ua] < mn[ua] or p[ua] > mx[ua] or p[va] < mn[va] or p[va] > mx[va]:
+        return None
+    on = tuple(f32(1.0) if k == axis else f32(0.0) for k in range(3))
+    front = dot(d, on) < f32(0.0)
+    return {"t": t, "p": p, "on": on, "front": front, "n": on if front else neg(on),
+            "uv": ((p[ua] - mn[ua]) / (mx[ua] - mn[ua]), (p[va] - mn[va]) / (mx[va] - mn[va]))}
+
+
+def translate_hit(offset, inner_hit, o, d, t_min, t_max):  # Translate::hit hitable.rs:409-418
+    h = inner_hit(sub(o, offset), d, t_min, t_max)
+    if h is not None:
+        h["p"] = add(h["p"], offset)
+    return h
+
+
+def constant_medium_hit(boundary_hit, neg_inv_density, o, d, t_min, t_max, xi):
+    """ConstantMedium::hit (hitable.rs:536-579) over any boundary; xi = the uniform draw of hitable.rs:564."""
+    inf = f32(np.inf)
+    r1 = boundary_hit(o, d, -inf, inf)
+    if r1 is None:
+        return None
+    r2 = boundary_hit(o, d, r1["t"] + f32(0.0001), inf)
+    if r2 is None:
+        return None
+    t1, t2 = r1["t"], r2["t"]
+    if t1 < t_min:
+        t1 = t_min
+    if t2 > t_max:
+        t2 = t_max
+    if t1 >= t2:
+        return None
+    if t1 < f32(0.0):
+        t1 = f32(0.0)
+    ray_len = length(d)
+    dist_inside = (t2 - t1) * ray_len
+    hit_dist = neg_inv_density * f32(np.log(xi))
+    if hit_dist > dist_inside:
+        return None
+    t = t1 + hit_dist / ray_len
+    nx = v3(1, 0, 0)  # hitable.rs:574-575: rec.norm = Vec3A::X, front_face = true
+    return {"t": t, "p": add(o, scale(d, t)), "on": nx, "front": True, "n": nx}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # texture.rs
 # ---------------------------------------------------------------------------------------------------------------
@@ -420,12 +471,28 @@ def sky_gradient(d):  # demo_scene.rs:28-31
 def bounce(case, o, d, key, depth):
     """main.rs:44-58 for one segment against ONE sphere (optionally under a RotateY wrapper), gradient sky.
     case: dict(c, r, mat, rot=(sin, cos) or None, tex_eval=callable(rec) -> rgb or None)."""
-    c, r = v3(*case["c"]), f32(case["r"])
     tmax = f32(np.finfo(np.float32).max)
+    if case.get("rect"):  # an axis-aligned rectangle below a Translate
+        rc = case["rect"]
+        mn, mx, off = v3(*rc["min"]), v3(*rc["max"]), v3(*rc["offset"])
+        h = translate_hit(off, lambda ro, rd, a, b: rect_hit(rc["axis"], mn, mx, ro, rd, a, b), o, d, f32(1e-3), tmax)
+        return _finish(case, h, d, key, depth)
+    c, r = v3(*case["c"]), f32(case["r"])
+    if case.get("medium"):  # ConstantMedium over the sphere; its free-path draw is counter slot 224 + medium index
+        g = Rng(key[0], key[1], depth)
+        g.ctr += 224
+        xi = g.next()
+        h = constant_medium_hit(lambda ro, rd, a, b: sphere_hit(c, r, ro, rd, a, b), f32(case["medium"]["neg_inv_density"]),
+                                o, d, f32(1e-3), tmax, xi)
+        return _finish(case, h, d, key, depth)
     if case.get("rot"):
         h = rotate_y_sphere_hit(f32(case["rot"][0]), f32(case["rot"][1]), c, r, o, d, f32(1e-3), tmax)
     else:
         h = sphere_hit(c, r, o, d, f32(1e-3), tmax)
+    return _finish(case, h, d, key, depth)
+
+
+def _finish(case, h, d, key, depth):
     if h is None:
         return {"hit": -1, "t": f32(0), "alive": False, "att": v3(1, 1, 1), "o": ZERO, "d": ZERO, "rad": sky_gradient(d)}
     mat = dict(case["mat"])
