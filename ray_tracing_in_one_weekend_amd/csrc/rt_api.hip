@@ -604,7 +604,9 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         if (dd.y < 0 && dd.y != INT_MIN) dd.y = ~(int)entry_ids[(size_t)~dd.y];
     }
     std::vector<uint8_t> sclass(n_entries);
-    std::vector<float4> srec((size_t)n_entries * 5);
+    // (at least one record: shade() issues the loads of record 0 for a miss too, see rt_device.h, so an empty scene
+    // still needs 5 readable float4)
+    std::vector<float4> srec((size_t)std::max<uint32_t>(n_entries, 1u) * 5, make_float4(0.f, 0.f, 0.f, 0.f));
     bool class_present[RT_NCLASS] = {};
     class_present[0] = true; // "miss"
     for (uint32_t i = 0; i < n_entries; ++i) {

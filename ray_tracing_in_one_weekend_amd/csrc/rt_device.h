@@ -503,21 +503,30 @@ struct Bounce {
 // hit < 0: miss -> sky.  Otherwise rebuild the HitRecord (hitable.rs:93-99) and run
 // emitted + scatter of the material (material.rs, pbr.rs).
 // RECTS = false compiles the rectangle branches out (scenes without rectangles: 2 % faster).
-template <bool RECTS>
+// `after_record_loads()` is called once, right after the loads of the primitive record have been issued: k_shade
+// requests the NEXT segment's rays there.  Vector-memory results return in issue order (one vmcnt counter), so a
+// prefetch issued BEFORE the record loads would have to complete before the record can be used — its HBM latency would
+// sit in front of the shading instead of under it.
+struct NoPrefetch {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <bool RECTS, class AfterLoads = NoPrefetch>
 __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro, V3 rd, int hit, float t, Rng& rng,
-                               uint32_t& n_fetch) {
+                               uint32_t& n_fetch, AfterLoads after_record_loads = AfterLoads()) {
     Bounce out;
     out.radiance = splat(0.0f);
     out.attenuation = splat(1.0f);
     out.o = splat(0.0f);
     out.d = splat(0.0f);
     out.alive = false;
+    // (the record of entry 0 for a miss: every lane of the wave issues the same loads before the prefetch)
+    const float4* rec = sc.sph_rec + 5u * (uint32_t)(hit < 0 ? 0 : hit);
+    const float4 g = rec[0], r1 = rec[1], r2 = rec[2];
+    after_record_loads();
     if (hit < 0) {
         out.radiance = sky_value(sc, rd, n_fetch); // main.rs:58
         return out;
     }
-    const float4* rec = sc.sph_rec + 5u * (uint32_t)hit;
-    const float4 g = rec[0], r1 = rec[1];
     const bool is_medium = RECTS && (uint32_t)hit >= sc.n_prims;
     const bool is_rect = RECTS && !is_medium && (uint32_t)hit >= sc.n_spheres;
     // RECTS also stands for "general scene": the primitive may sit below Translate / RotateY wrappers.  The
@@ -577,14 +586,12 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     struct {
         uint32_t type, tex1;
         const float4* rec;
-        __device__ __forceinline__ float p0() const { return rec[2].w; }
+        float4 r2;
+        __device__ __forceinline__ float p0() const { return r2.w; }
         __device__ __forceinline__ float p1() const { return rec[3].x; }
         __device__ __forceinline__ float p2() const { return rec[3].y; }
-        __device__ __forceinline__ V3 color() const {
-            const float4 c = rec[2];
-            return v3(c.x, c.y, c.z);
-        }
-    } m{__float_as_uint(r1.x), __float_as_uint(r1.w), rec};
+        __device__ __forceinline__ V3 color() const { return v3(r2.x, r2.y, r2.z); }
+    } m{__float_as_uint(r1.x), __float_as_uint(r1.w), rec, r2};
     const uint32_t t0type = __float_as_uint(r1.y), t0aux = __float_as_uint(r1.z);
     // Every texture-bearing material evaluates its first texture exactly once at (uv(on), p), and
     // Texture::value draws no random numbers, so it is evaluated here, at ONE call site (the 7-octave

@@ -1022,7 +1022,12 @@ __global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const 
         for (uint32_t seg = 0; seg < n_here; seg += 64u) {
             float2 hB = make_float2(0.0f, 0.0f), rcB = hB;
             float4 raB = make_float4(0.f, 0.f, 0.f, 0.f), rbB = raB;
-            if (seg + 64u < n_here) fetch(seg + 64u, hB, raB, rbB, rcB);
+            bool prefetched = false;
+            // the next segment's rays: requested from inside shade(), behind the loads of this segment's primitive records
+            auto prefetch = [&]() {
+                if (!prefetched && seg + 64u < n_here) fetch(seg + 64u, hB, raB, rbB, rcB);
+                prefetched = true;
+            };
             const uint32_t j = seg + lane;
             bool alive = false;
             Bounce bo;
@@ -1073,7 +1078,7 @@ __global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const 
                     ++n_bad;
                 } else {
                     Rng rng{k0, k1, depth_counter_base(tp.depth)};
-                    bo = shade<RECTS>(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch);
+                    bo = shade<RECTS>(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch, prefetch);
                     if (bo.alive && tp.russian_roulette) { // main.rs:49-53
                         const float rr = rng.next();
                         rr_threshold = fmaxf(bo.attenuation.x, fmaxf(bo.attenuation.y, bo.attenuation.z)); // max_element
@@ -1088,6 +1093,7 @@ __global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const 
                 // one 16 B store: beyond depth 0 the slots of a wave are scattered
                 if (!alive) rad[slot] = make_float4(Lr.x, Lr.y, Lr.z, 0.0f);
             }
+            prefetch(); // (lanes that shaded nothing: beyond the block, or a direction the reference would panic on)
             // wave64 compaction: ballot + prefix popcount; the wave claims its slots from the LDS counter
             const unsigned long long mask = __ballot(alive);
             if (mask) {
