@@ -418,6 +418,23 @@ __device__ __forceinline__ void closest_hit_spheres_general(const DevScene& sc, 
 
 #define RT_BVH_BLOCK 1024 // threads per workgroup of k_intersect (one LDS copy of the tree)
 #define RT_BVH_MAX_DEPTH 64u
+// Lane statistics of the traversal (diagnostic builds only, -DRT_PROFILE_LANES; scripts/gpu_lane_stats.py): for each
+// counted site, [i] += 64 per trip of a wave and [i + 1] += the lanes that were active in it.
+//   0/1 main-loop trips / lanes holding a ray   2/3 node steps   4/5 trips of the leaf loop   6/7 refill blocks / lanes refilled
+#ifdef RT_PROFILE_LANES
+__device__ unsigned long long g_lane_stats[8];
+#define RT_LANE_STAT(I, PRED)                                                                      \
+    do {                                                                                           \
+        const unsigned long long act_ = __ballot(true), m_ = __ballot(PRED);                       \
+        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)act_) - 1u) {                      \
+            atomicAdd(&g_lane_stats[I], 64ull);                                                    \
+            atomicAdd(&g_lane_stats[(I) + 1], (unsigned long long)__popcll(m_));                   \
+        }                                                                                          \
+    } while (0)
+#else
+#define RT_LANE_STAT(I, PRED)
+#endif
+
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 48 // a wave refills from the queue when at least this many lanes are idle
                          // (measured: 8 -> 16.9 ms, 16 -> 15.6, 48 -> 14.7, 64 -> 16.0 per 337 M rays)
@@ -580,6 +597,7 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
                                          float noz, float eps, bool exact, float a, uint32_t& pend, int& cur, int& sp,
                                          float& tbest, int& hit) {
     { // leaves never reach the stack (they are tested inside the node step below): cur is always a node
+        RT_LANE_STAT(2, true);
         const float4 mnx = L.pl[0][cur], mny = L.pl[1][cur], mnz = L.pl[2][cur];
         const float4 mxx = L.pl[3][cur], mxy = L.pl[4][cur], mxz = L.pl[5][cur];
         const int4 id = L.id[cur];
@@ -632,6 +650,7 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
         ChainCache cc;
         cc.xf = RT_NO_XFORM_DEV;
         while (lq0 != 0u) {
+            RT_LANE_STAT(4, true);
             const int s = (int)(lq0 & 0xFFFFu) - 1;
             lq0 = (lq0 >> 16) | (lq1 << 16);
             lq1 >>= 16;
@@ -714,7 +733,9 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!GEN) RT_LANE_STAT(0, has);
         if (n_idle >= RT_REFILL_MIN && !exhausted) {
+            if (!GEN) RT_LANE_STAT(6, !has);
             uint32_t v0 = 0;
             if (lane == 0) v0 = atomicAdd(s_work, n_idle); // LDS atomic: claim n_idle rays
             v0 = __builtin_amdgcn_readfirstlane(v0);
