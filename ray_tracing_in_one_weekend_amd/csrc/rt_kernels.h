@@ -592,14 +592,26 @@ __device__ __forceinline__ void leaf_test(const BvhLds& L, int s, V3 o, V3 d, fl
 // slack grows to the size of the scene (a direction component below ~1e-4: o*inv cancels against b*inv
 // and nothing is culled any more — harmless for a tree in LDS, milliseconds for one wave walking 1 000
 // nodes out of HBM) `exact` selects (b - o)*inv, which has no cancellation, with eps = 0.
-template <int BLOCK, bool RECTS>
+// The near / far plane arrays of one ray (SORTED node steps, tree in LDS): per axis, the array of the child-box planes
+// the ray reaches first and the array of those it leaves through, chosen once per ray by the sign of 1/d.
+struct SlabPlanes {
+    const float4 *nx, *ny, *nz, *fx, *fy, *fz;
+};
+// SORTED: `sp6` holds this ray's near / far plane arrays.  b*inv + c is monotone in b, so for a finite non-zero inv the
+// smaller of the two plane distances of a slab is the one of the near plane: the six min / max per child that order them
+// (24 of the ~120 vector instructions of a node step) go away.  Only the fma form relies on it — `exact` rays (inv
+// infinite or NaN among them, see k_intersect) still order the two distances with min / max, which does not care which
+// array a value came from.
+template <int BLOCK, bool RECTS, bool SORTED = false>
 __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float nox, float noy,
                                          float noz, float eps, bool exact, float a, uint32_t& pend, int& cur, int& sp,
-                                         float& tbest, int& hit) {
+                                         float& tbest, int& hit, const SlabPlanes* sp6 = nullptr) {
     { // leaves never reach the stack (they are tested inside the node step below): cur is always a node
         RT_LANE_STAT(2, true);
-        const float4 mnx = L.pl[0][cur], mny = L.pl[1][cur], mnz = L.pl[2][cur];
-        const float4 mxx = L.pl[3][cur], mxy = L.pl[4][cur], mxz = L.pl[5][cur];
+        const float4 mnx = SORTED ? sp6->nx[cur] : L.pl[0][cur], mny = SORTED ? sp6->ny[cur] : L.pl[1][cur],
+                     mnz = SORTED ? sp6->nz[cur] : L.pl[2][cur];
+        const float4 mxx = SORTED ? sp6->fx[cur] : L.pl[3][cur], mxy = SORTED ? sp6->fy[cur] : L.pl[4][cur],
+                     mxz = SORTED ? sp6->fz[cur] : L.pl[5][cur];
         const int4 id = L.id[cur];
         const float tb = __builtin_fmaf(tbest, 1.000004f, eps);
         uint32_t lq0 = 0u, lq1 = 0u; // the hit leaf children of this node, entry id + 1 in 16 bits each
@@ -610,8 +622,10 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
         const float x0 = RT_T(mnx.K, ix, nox, o.x), x1 = RT_T(mxx.K, ix, nox, o.x);                           \
         const float y0 = RT_T(mny.K, iy, noy, o.y), y1 = RT_T(mxy.K, iy, noy, o.y);                           \
         const float z0 = RT_T(mnz.K, iz, noz, o.z), z1 = RT_T(mxz.K, iz, noz, o.z);                           \
-        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));              \
-        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));                           \
+        const float tn = RT_ORDERED ? fmaxf(fmaxf(x0, y0), fmaxf(z0, 0.0f))                                   \
+                                    : fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f)); \
+        const float tf = RT_ORDERED ? fminf(fminf(x1, y1), z1)                                                \
+                                    : fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));              \
         if (tn <= fminf(__builtin_fmaf(tf, 1.000004f, eps), tb) && IDK != (int)0x80000000) {                  \
             if (IDK < 0) { /* a leaf: queued for the leaf loop behind the four box tests */                   \
                 lq1 = (lq1 << 16) | (lq0 >> 16);                                                               \
@@ -631,17 +645,21 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
     }
         if (!exact) {
 #define RT_T(B, INV, NO, O) __builtin_fmaf(B, INV, NO)
+#define RT_ORDERED SORTED
             RT_CHILD(x, id.x)
             RT_CHILD(y, id.y)
             RT_CHILD(z, id.z)
             RT_CHILD(w, id.w)
+#undef RT_ORDERED
 #undef RT_T
         } else { // rays almost parallel to an axis plane (see k_intersect): plane distances without cancellation
 #define RT_T(B, INV, NO, O) (((B) - (O)) * (INV))
+#define RT_ORDERED false
             RT_CHILD(x, id.x)
             RT_CHILD(y, id.y)
             RT_CHILD(z, id.z)
             RT_CHILD(w, id.w)
+#undef RT_ORDERED
 #undef RT_T
         }
 #undef RT_CHILD
@@ -730,6 +748,10 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
     int hit = -1, cur = 0, sp = 0;
     size_t pos = 0;
     MediumCtx mc{0u, 0u, depth_counter_base(ip.depth)};
+    // Sorted slab planes for sphere-only scenes with the tree in LDS.  General scenes: the six extra registers spill in the
+    // 64-VGPR kernels (cornell_box +3 %, simple_light_scene +4 % measured); a tree in HBM would need six 64-bit pointers.
+    constexpr bool SORTED = LDS_NODES && !RECTS;
+    SlabPlanes planes{L.pl[0], L.pl[1], L.pl[2], L.pl[3], L.pl[4], L.pl[5]}; // SORTED: this ray's near / far arrays
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -777,6 +799,11 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 eps = 2.4e-7f * fmaxf(fmaxf(fabsf(nox), fabsf(noy)), fabsf(noz));
                 exact = !(eps <= sc.bvh_exact_eps); // also NaN (0 * inf)
                 if (exact) eps = 0.0f;
+                if (SORTED) { // a negative 1/d enters the slab of that axis through its max plane
+                    planes.nx = ix < 0.0f ? L.pl[3] : L.pl[0], planes.fx = ix < 0.0f ? L.pl[0] : L.pl[3];
+                    planes.ny = iy < 0.0f ? L.pl[4] : L.pl[1], planes.fy = iy < 0.0f ? L.pl[1] : L.pl[4];
+                    planes.nz = iz < 0.0f ? L.pl[5] : L.pl[2], planes.fz = iz < 0.0f ? L.pl[2] : L.pl[5];
+                }
                 a = length_squared(d); // hitable.rs:77
                 tbest = RT_FLT_MAX;
                 hit = -1;
@@ -821,7 +848,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 continue;
             }
         }
-        if (has && trav && bvh_step<BLOCK, RECTS>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit)) {
+        if (has && trav && bvh_step<BLOCK, RECTS, SORTED>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit, &planes)) {
             if (RECTS && pend) {
                 trav = false;
             } else {
