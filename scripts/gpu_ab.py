@@ -1,5 +1,6 @@
 """Interleaved A/B of library builds in ONE process on ONE device (cdna guide rule 24):
-python scripts/gpu_ab.py <spp> <rounds> libA.so libB.so ...   -> median isect/shade/total ms per variant"""
+python scripts/gpu_ab.py <spp> <rounds> libA.so libB.so ...   -> median isect/shade/total ms per variant
+(RTOW_SCENE=name picks the scene, RTOW_AB_DEPTHS=N adds the per-depth split of the first N depths)"""
 import ctypes
 import os
 import statistics
@@ -22,13 +23,24 @@ for path in libs:
     rends.append(r)
 p = rt.make_params(1920, 1080, spp, max_depth=50, flags=rt._ffi.FLAG_TIME_DEPTHS)
 res = {i: [] for i in range(len(libs))}
+per_depth = {i: [] for i in range(len(libs))}
 for it in range(rounds + 1):
     for i, r in enumerate(rends):
         img, _, st = r.render(scene.camera, p)
         a, b, n = r.depth_timings()
         if it:  # first round = warm-up
             res[i].append((a.sum(), b.sum(), st.seconds_device * 1e3, st.n_rays))
+            per_depth[i].append((a.copy(), b.copy()))
 for i, path in enumerate(libs):
     a = statistics.median(x[0] for x in res[i]); b = statistics.median(x[1] for x in res[i]); t = statistics.median(x[2] for x in res[i])
     print(f"{os.path.basename(path):40s} isect {a:7.2f} ms  shade {b:7.2f} ms  device {t:7.2f} ms  rays {res[i][0][3]}  "
           f"-> {res[i][0][3] / t / 1e3:8.0f} Mray/s")
+# RTOW_AB_DEPTHS=N: the first N depths (median ms of k_intersect / k_shade per variant) and the rest as one line
+nd = int(os.environ.get("RTOW_AB_DEPTHS", "0"))
+if nd:
+    import numpy as np
+    med = [(np.median([x[0] for x in per_depth[i]], axis=0), np.median([x[1] for x in per_depth[i]], axis=0)) for i in range(len(libs))]
+    print("depth  " + "  ".join(f"{os.path.basename(p)[:18]:>18s} isect/shade" for p in libs))
+    for d in range(min(nd, len(med[0][0]))):
+        print(f"{d:5d}  " + "  ".join(f"{m[0][d]:18.3f} /{m[1][d]:8.3f}  " for m in med))
+    print(" rest  " + "  ".join(f"{m[0][nd:].sum():18.3f} /{m[1][nd:].sum():8.3f}  " for m in med))

@@ -211,6 +211,25 @@ def test_render_full_depth_and_slicing_invariance(rt, orc, renderer):
         assert np.array_equal(im2.view(np.uint32), img.view(np.uint32))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nx,ny", [("sphere_scene", 96, 54), ("cornell_box", 48, 48)])
+def test_many_samples_and_uneven_slices(rt, orc, renderer, name, nx, ny):
+    """150 samples per pixel against the oracle, then in slices of 70 + 70 + 10, 64 + 64 + 22 and 128 + 22 samples: the
+    sample sum is taken in sample order whatever the slicing, so the frames are bit-identical (the layouts of the path
+    slots that were tried on top of this test: scripts/experiments/pixel_major_sample_blocks.patch)."""
+    scene = rt.Scene.build(name, nx / ny)
+    renderer.upload(scene)
+    p = rt.make_params(nx, ny, 150, max_depth=12)
+    img, _, st = renderer.render(scene.camera, p)
+    ref, _, so = _oracle(orc, scene, p)
+    assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
+    _compare_frames(orc, scene, p, img, ref, name)
+    for s in (70, 64, 128):
+        im2, _, st2 = renderer.render(scene.camera, rt.make_params(nx, ny, 150, max_depth=12, spp_slice=s))
+        assert st2.n_slices == (150 + s - 1) // s and st2.n_rays == st.n_rays
+        assert np.array_equal(im2.view(np.uint32), img.view(np.uint32)), s
+
+
 def test_render_sharding_is_bit_invariant(rt, renderer):
     scene = rt.Scene.build("sphere_scene", 16 / 9)
     renderer.upload(scene)
