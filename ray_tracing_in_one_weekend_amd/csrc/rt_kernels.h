@@ -780,8 +780,11 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 // sphere-only scene with candidate lists: k_shade<GEN> finds the closest hit of a listed pixel itself;
                 // only the rays of pixels whose list overflowed are traced (and recorded) here
                 bool skip = false;
-                if (GEN && !RECTS && gpd->lists)
-                    skip = (gpd->lists[primary_idx_of(ip.nq, shard, off) % gpd->npix].x & 0xFFFFu) != RT_LIST_OVERFLOW;
+                if (GEN && !RECTS && gpd->lists) {
+                    uint32_t pl; // local pixel of the slot (udiv_inv: a true 32-bit modulo is ~40 instructions)
+                    udiv_inv(primary_idx_of(ip.nq, shard, off), gpd->npix, gpd->inv_npix, pl);
+                    skip = (gpd->lists[pl].x & 0xFFFFu) != RT_LIST_OVERFLOW;
+                }
                 if (!skip) {
                 if (GEN) {
                     uint32_t k0, k1, pl;
@@ -940,7 +943,9 @@ struct ShadeParams {
 // exact Sphere::hit roots of its <= 7 entries, same winner rule as the tree — so a primary ray is generated once and
 // no hit record travels through HBM; k_intersect<GEN> then only traces the rays of pixels whose list overflowed.
 #define RT_PERLIN_LDS_MAX_SETS 4u
+#ifndef RT_SORT_N
 #define RT_SORT_N 512u  // rays per wave-local counting sort (8 segments of 64)
+#endif
 #define RT_NCLASS 64u
 #define RT_CLASS_LDS_MAX 4096u // scenes up to this many world entries keep their class table in LDS
 #define RT_SHADE_WAVE_LDS (RT_NCLASS * 4u + RT_SORT_N * 8u + RT_SORT_N * 2u) // histogram, sorted records, positions
