@@ -190,6 +190,23 @@ void launch_shade(RtCtx* ctx, hipStream_t sg, bool gen, bool fused_lists, uint32
 #undef RT_LAUNCH_SHADE
 }
 
+// The work buffers of one ray queue (k = 0, 1) and the view the kernels get: qbuf[3k] holds the a / b records
+// (interleaved when RT_QSTRIDE is 2; qbuf[3k + 1] is the separate b array of the RT_QSTRIDE 1 build), qbuf[3k + 2] the c array.
+int ensure_queues(RtCtx* ctx, size_t n_rays) {
+    const size_t qbytes = n_rays * sizeof(float4);
+    for (int k = 0; k < 2; ++k) {
+        int rc;
+        if ((rc = ensure(ctx, ctx->qbuf[3 * k], RT_QSTRIDE * qbytes))) return rc;
+        if (RT_QSTRIDE == 1u && (rc = ensure(ctx, ctx->qbuf[3 * k + 1], qbytes))) return rc;
+        if ((rc = ensure(ctx, ctx->qbuf[3 * k + 2], qbytes / 2))) return rc;
+    }
+    return RT_OK;
+}
+Queue queue_view(RtCtx* ctx, int k) {
+    float4* a = (float4*)ctx->qbuf[3 * k].p;
+    return Queue{a, RT_QSTRIDE == 1u ? (float4*)ctx->qbuf[3 * k + 1].p : a + 1, (float2*)ctx->qbuf[3 * k + 2].p};
+}
+
 // Queue geometry of a slice of n_max rays: shard count, k_intersect grid, shard capacity.
 struct QueueGeom {
     uint32_t nq, isect_grid, cap;
@@ -759,9 +776,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     // depth 0 regenerates the primary ray in both kernels instead of materialising the queue
     const bool fuse_gen = use_bvh && !getenv("RTOW_NO_FUSE_GEN");
 
-    const size_t qbytes = (size_t)nq * cap * sizeof(float4);
-    for (int k = 0; k < 6; ++k)
-        if ((rc = ensure(ctx, ctx->qbuf[k], k % 3 == 2 ? qbytes / 2 : qbytes))) return rc;
+    if ((rc = ensure_queues(ctx, (size_t)nq * cap))) return rc;
     if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
     if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * sizeof(float4)))) return rc;
     if ((rc = ensure(ctx, ctx->acc, (size_t)npix * 3 * sizeof(float)))) return rc;
@@ -776,9 +791,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         RT_HIP(ctx, hipEventCreate(&ev));
         ctx->events.push_back(ev);
     }
-    Queue Q[2];
-    Q[0] = Queue{(float4*)ctx->qbuf[0].p, (float4*)ctx->qbuf[1].p, (float2*)ctx->qbuf[2].p};
-    Q[1] = Queue{(float4*)ctx->qbuf[3].p, (float4*)ctx->qbuf[4].p, (float2*)ctx->qbuf[5].p};
+    const Queue Q[2] = {queue_view(ctx, 0), queue_view(ctx, 1)};
     float2* qhit = (float2*)ctx->qhit.p;
     float4* rad = (float4*)ctx->rad.p;
     float* acc = (float*)ctx->acc.p;
@@ -1003,17 +1016,14 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
     const QueueGeom qg = queue_geom(ctx, n);
     const uint32_t nq = qg.nq, cap = qg.cap;
     int rc;
-    const size_t qbytes = (size_t)nq * cap * sizeof(float4);
-    for (int k = 0; k < 6; ++k)
-        if ((rc = ensure(ctx, ctx->qbuf[k], k % 3 == 2 ? qbytes / 2 : qbytes))) return rc;
+    if ((rc = ensure_queues(ctx, (size_t)nq * cap))) return rc;
     if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
     if ((rc = ensure(ctx, ctx->rad, (size_t)n * sizeof(float4)))) return rc;
     if ((rc = ensure(ctx, ctx->counts, (size_t)2 * nq * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->totals, 4 * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->genp, sizeof(GenParams)))) return rc;
     if ((rc = ensure(ctx, ctx->dbg, (size_t)n * 6 * sizeof(float)))) return rc;
-    Queue Q[2] = {Queue{(float4*)ctx->qbuf[0].p, (float4*)ctx->qbuf[1].p, (float2*)ctx->qbuf[2].p},
-                  Queue{(float4*)ctx->qbuf[3].p, (float4*)ctx->qbuf[4].p, (float2*)ctx->qbuf[5].p}};
+    const Queue Q[2] = {queue_view(ctx, 0), queue_view(ctx, 1)};
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     float* d_o = (float*)ctx->dbg.p;
     float* d_d = d_o + 3 * (size_t)n;
@@ -1043,12 +1053,19 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
     std::vector<float2> hc((size_t)nq * cap), hh((size_t)nq * cap);
     std::vector<uint32_t> hcnt((size_t)2 * nq);
     RT_HIP(ctx, hipMemcpyAsync(hh.data(), ctx->qhit.p, hh.size() * sizeof(float2), hipMemcpyDeviceToHost, st));
-    RT_HIP(ctx, hipMemcpyAsync(ha.data(), Q[1].a, ha.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
-    RT_HIP(ctx, hipMemcpyAsync(hb.data(), Q[1].b, hb.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
+    std::vector<float4> hab; // RT_QSTRIDE 2: the interleaved a / b records, split on the host below
+    if (RT_QSTRIDE == 1u) {
+        RT_HIP(ctx, hipMemcpyAsync(ha.data(), Q[1].a, ha.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
+        RT_HIP(ctx, hipMemcpyAsync(hb.data(), Q[1].b, hb.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
+    } else {
+        hab.resize(2 * ha.size());
+        RT_HIP(ctx, hipMemcpyAsync(hab.data(), Q[1].a, hab.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
+    }
     RT_HIP(ctx, hipMemcpyAsync(hc.data(), Q[1].c, hc.size() * sizeof(float2), hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipMemcpyAsync(hrad.data(), ctx->rad.p, hrad.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipMemcpyAsync(hcnt.data(), counts, hcnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipStreamSynchronize(st));
+    for (size_t i = 0; i < hab.size() / 2; ++i) ha[i] = hab[2 * i], hb[i] = hab[2 * i + 1];
     auto bits = [](float f) {
         uint32_t u;
         std::memcpy(&u, &f, 4);

@@ -16,7 +16,7 @@
 // Ray queue layout in HBM (SoA, 40 B per ray: two 16 B arrays that k_intersect reads and an 8 B one that only
 // k_shade needs), plus an 8 B hit record per ray between the kernels:
 //   qa[i] = (o.x, o.y, o.z, slot)   slot = path slot of the slice = s_local * npix + pixel_local
-//   qb[i] = (d.x, d.y, d.z, T.x)    T = path throughput
+//   qb[i] = (d.x, d.y, d.z, T.x)    T = path throughput          (qa and qb interleaved: one 32 B record, struct Queue)
 //   qc[i] = (T.y, T.z)
 //   qh[i] = (t, entry index)        written by k_intersect, read by k_shade
 // The per-path RNG key (k0, k1) is a pure function of (seed, pixel, sample), i.e. of the slot: it is recomputed
@@ -32,6 +32,13 @@
 
 namespace rt {
 
+// a / b interleaved (RT_QSTRIDE 2: b = a + 1, ray i at a[2 i] and b[2 i]): one 32 B record (o, slot, d, T.x) per ray.
+// k_intersect streams through it exactly as through two arrays.  k_shade gathers rays in class order: a 128 B line
+// now holds 4 rays instead of 8, so fewer class segments of the sort window come back to it after it has left the
+// L2, and one fetched line serves both halves of the ray.
+#ifndef RT_QSTRIDE
+#define RT_QSTRIDE 2u
+#endif
 struct Queue {
     float4* a;
     float4* b;
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q) {
     const uint32_t chunk = idx >> 8;
     const uint32_t sq = chunk % gp.nq;
     const size_t pos = (size_t)sq * gp.cap + (size_t)(chunk / gp.nq) * 256u + (idx & 255u);
-    q.a[pos] = make_float4(o.x, o.y, o.z, __uint_as_float(idx));
-    q.b[pos] = make_float4(d.x, d.y, d.z, 1.0f);
+    q.a[RT_QSTRIDE * pos] = make_float4(o.x, o.y, o.z, __uint_as_float(idx));
+    q.b[RT_QSTRIDE * pos] = make_float4(d.x, d.y, d.z, 1.0f);
     q.c[pos] = make_float2(1.0f, 1.0f);
 }
 
@@ -792,7 +799,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                     if (RECTS) mc.k0 = k0, mc.k1 = k1;
                     if (gpd->lists) list = gpd->lists[pl];
                 } else {
-                    const float4 ra = qa[pos], rb = qb[pos];
+                    const float4 ra = qa[RT_QSTRIDE * pos], rb = qb[RT_QSTRIDE * pos];
                     o = v3(ra.x, ra.y, ra.z);
                     d = v3(rb.x, rb.y, rb.z);
                     if (RECTS && sc.n_media) path_key_of_slot(*gpd, __float_as_uint(ra.w), mc.k0, mc.k1); // the free-path draw
@@ -884,7 +891,7 @@ __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float
         const bool active = i < count;
         V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
         if (active) {
-            const float4 ra = qa[qbase + i], rb = qb[qbase + i];
+            const float4 ra = qa[RT_QSTRIDE * (qbase + i)], rb = qb[RT_QSTRIDE * (qbase + i)];
             o = v3(ra.x, ra.y, ra.z);
             d = v3(rb.x, rb.y, rb.z);
         }
@@ -905,7 +912,7 @@ __global__ __launch_bounds__(256) void k_intersect_list(DevScene sc, const float
             }
         }
         MediumCtx mc{0u, 0u, depth_counter_base(ip.depth)};
-        if (active && sc.n_media) path_key_of_slot(*gpd, __float_as_uint(qa[qbase + i].w), mc.k0, mc.k1);
+        if (active && sc.n_media) path_key_of_slot(*gpd, __float_as_uint(qa[RT_QSTRIDE * (qbase + i)].w), mc.k0, mc.k1);
         closest_hit_rects(sc, o, d, mc, tbest, hit);
         if (active) qh[qbase + i] = make_float2(tbest, __int_as_float(hit));
     }
@@ -1068,7 +1075,7 @@ __global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const 
                 if (sort) h = s_rec[j], pj = s_pos[j];
                 else h = qh[qbase + base + j];
                 const size_t r = qbase + base + pj;
-                ra = qin.a[r], rb = qin.b[r], rc = qin.c[r];
+                ra = qin.a[RT_QSTRIDE * r], rb = qin.b[RT_QSTRIDE * r], rc = qin.c[r];
             }
         };
         fetch(0u, hA, raA, rbA, rcA);
@@ -1162,8 +1169,8 @@ __global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const 
 #endif
                     V3 Tn = T * bo.attenuation;
                     if (tp.russian_roulette) Tn = Tn / rr_threshold; // (T * a) / threshold
-                    qout.a[pos] = make_float4(bo.o.x, bo.o.y, bo.o.z, __uint_as_float(slot));
-                    qout.b[pos] = make_float4(bo.d.x, bo.d.y, bo.d.z, Tn.x);
+                    qout.a[RT_QSTRIDE * pos] = make_float4(bo.o.x, bo.o.y, bo.o.z, __uint_as_float(slot));
+                    qout.b[RT_QSTRIDE * pos] = make_float4(bo.d.x, bo.d.y, bo.d.z, Tn.x);
                     qout.c[pos] = make_float2(Tn.y, Tn.z);
                 }
             }
@@ -1242,8 +1249,8 @@ __global__ __launch_bounds__(256) void k_debug_fill(GenParams gp, Queue q, const
     if (idx >= gp.n_rays) return;
     const uint32_t chunk = idx >> 8;
     const size_t pos = (size_t)(chunk % gp.nq) * gp.cap + (size_t)(chunk / gp.nq) * 256u + (idx & 255u);
-    q.a[pos] = make_float4(in_o[3 * idx], in_o[3 * idx + 1], in_o[3 * idx + 2], __uint_as_float(idx));
-    q.b[pos] = make_float4(in_d[3 * idx], in_d[3 * idx + 1], in_d[3 * idx + 2], 1.0f);
+    q.a[RT_QSTRIDE * pos] = make_float4(in_o[3 * idx], in_o[3 * idx + 1], in_o[3 * idx + 2], __uint_as_float(idx));
+    q.b[RT_QSTRIDE * pos] = make_float4(in_d[3 * idx], in_d[3 * idx + 1], in_d[3 * idx + 2], 1.0f);
     q.c[pos] = make_float2(1.0f, 1.0f);
 }
 
