@@ -15,6 +15,15 @@ step() { # step <seconds> <command...>
   return 0
 }
 step 120 ./scripts/micro/mul_rate $out/valu_peak.json > $out/mul_rate.txt 2>&1
+# The PMC passes first: bench.py quotes roofline.traffic / roofline.valu from profiles/round*/, so the files of THIS library
+# have to be in place (in this box's copy of the repo; copy them into the tracked profiles/ afterwards) before the bench lines run.
+prof=$(ls -d profiles/round* | sort -V | tail -1)
+cp $out/valu_peak.json $prof/valu_peak.json
+step 400 $py scripts/collect_traffic.py $out/traffic_config2.json > $out/traffic_config2.log 2>&1
+step 400 $py scripts/collect_valu.py $out/valu_config2.json > $out/valu_config2.log 2>&1
+step 400 $py scripts/collect_traffic.py $out/traffic_config4.json --config 4 --steps 1 --warmup 0 --no-cpu-baseline > $out/traffic_config4.log 2>&1
+step 400 $py scripts/collect_traffic.py $out/traffic_config5.json --config 5 --steps 1 --warmup 0 --no-cpu-baseline > $out/traffic_config5.log 2>&1
+cp $out/traffic_config2.json $out/traffic_config4.json $out/traffic_config5.json $out/valu_config2.json $prof/
 step 300 $py bench.py --steps 20 --warmup 5 > $out/bench_config2.json 2> $out/bench_config2.err
 for c in 3 4 5; do step 300 $py bench.py --config $c --steps 3 --warmup 1 > $out/bench_config$c.json 2> $out/bench_config$c.err; done
 for c in 2 4 5; do
@@ -24,10 +33,6 @@ for c in 2 4 5; do
   find $out/prof_tmp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats_config$c.csv
 done
 rm -rf $out/prof_tmp
-step 400 $py scripts/collect_traffic.py $out/traffic_config2.json > $out/traffic_config2.log 2>&1
-step 400 $py scripts/collect_valu.py $out/valu_config2.json > $out/valu_config2.log 2>&1
-step 400 $py scripts/collect_traffic.py $out/traffic_config4.json --config 4 --steps 1 --warmup 0 --no-cpu-baseline > $out/traffic_config4.log 2>&1
-step 400 $py scripts/collect_traffic.py $out/traffic_config5.json --config 5 --steps 1 --warmup 0 --no-cpu-baseline > $out/traffic_config5.log 2>&1
 step 400 $py scripts/pmc_probe.py $out/pmc_probe_tmp "" 128 > $out/pmc_per_dispatch_config2_128spp.txt 2>&1
 rm -rf $out/pmc_probe_tmp gpurun_out/pmc_*
 step 300 $py scripts/gpu_scene_table.py 64 $out/scene_table.json > $out/scene_table.txt 2>&1
