@@ -1,6 +1,10 @@
 """Interleaved A/B of library builds in ONE process on ONE device (cdna guide rule 24):
 python scripts/gpu_ab.py <spp> <rounds> libA.so libB.so ...   -> median isect/shade/total ms per variant
-(RTOW_SCENE=name picks the scene, RTOW_AB_DEPTHS=N adds the per-depth split of the first N depths)"""
+(RTOW_SCENE=name picks the scene, RTOW_AB_DEPTHS=N adds the per-depth split of the first N depths)
+
+Position bias: the variant listed FIRST has been seen to read up to 0.5 ms (2-3 %) high on k_shade with two identical
+binaries (gpurun_out/r2/ab_rcp.txt).  List the baseline first AND last, or a copy of the candidate twice, and believe a
+difference only when it exceeds the spread between the identical copies."""
 import ctypes
 import os
 import statistics
