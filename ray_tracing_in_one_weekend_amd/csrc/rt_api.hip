@@ -1154,10 +1154,10 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
 #ifdef RT_PROFILE_LANES
 // Diagnostic builds only (not declared in include/rtow_mi355x.h, absent from the product library): the lane statistics
 // of rt_kernels.h, optionally reset after reading.
-extern "C" int rt_debug_lane_stats(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rt::g_lane_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+extern "C" int rt_debug_lane_stats(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rt::g_lane_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
-        const unsigned long long zero[8] = {};
+        const unsigned long long zero[16] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_lane_stats), zero, sizeof(zero)) != hipSuccess) return -1;
     }
     return 0;

@@ -73,6 +73,24 @@ __device__ __forceinline__ int32_t sat_i32(float f) {
     return (int32_t)f;
 }
 
+// Lane statistics (diagnostic builds only, -DRT_PROFILE_LANES; scripts/gpu_lane_stats.py): for each counted site,
+// [i] += 64 per trip of a wave and [i + 1] += the lanes that were active in it.
+//   k_intersect: 0/1 main-loop trips / lanes holding a ray   2/3 node steps   4/5 trips of the leaf loop   6/7 refill blocks
+//   shading:     8/9 trips of the rejection loop of random_in_unit_sphere   10/11 calls of it (lanes entering)
+#ifdef RT_PROFILE_LANES
+__device__ unsigned long long g_lane_stats[16];
+#define RT_LANE_STAT(I, PRED)                                                                      \
+    do {                                                                                           \
+        const unsigned long long act_ = __ballot(true), m_ = __ballot(PRED);                       \
+        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)act_) - 1u) {                      \
+            atomicAdd(&g_lane_stats[I], 64ull);                                                    \
+            atomicAdd(&g_lane_stats[(I) + 1], (unsigned long long)__popcll(m_));                   \
+        }                                                                                          \
+    } while (0)
+#else
+#define RT_LANE_STAT(I, PRED)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Counter-based RNG (DESIGN.md "RNG"); replaces the thread-local SmallRng of lib.rs:7-9.
 // draw(k0,k1,ctr) = fmix32(fmix32(k0 ^ ctr*0x9E3779B9) + k1); f32 = (u32 >> 8) * 2^-24 exactly
@@ -105,8 +123,12 @@ __device__ __forceinline__ uint32_t depth_counter_base(int depth) { return (uint
 // ---------------------------------------------------------------------------------------------
 // math.rs sampling and geometry helpers
 // ---------------------------------------------------------------------------------------------
+// (Measured with the counters above, profiles/round2/lane_stats_shading.txt: 6.0 trips per wave for 1.9 per lane, at 21 %
+// lane utilisation — a third of k_shade's vector instructions.  Two remedies were built and neither pays)
 __device__ __forceinline__ V3 random_in_unit_sphere(Rng& rng) { // math.rs:17-37
+    RT_LANE_STAT(10, true);
     for (;;) {
+        RT_LANE_STAT(8, true);
         float x = rng.next();
         float y = rng.next();
         float z = rng.next();

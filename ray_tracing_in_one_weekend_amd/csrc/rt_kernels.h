@@ -425,23 +425,6 @@ __device__ __forceinline__ void closest_hit_spheres_general(const DevScene& sc, 
 
 #define RT_BVH_BLOCK 1024 // threads per workgroup of k_intersect (one LDS copy of the tree)
 #define RT_BVH_MAX_DEPTH 64u
-// Lane statistics of the traversal (diagnostic builds only, -DRT_PROFILE_LANES; scripts/gpu_lane_stats.py): for each
-// counted site, [i] += 64 per trip of a wave and [i + 1] += the lanes that were active in it.
-//   0/1 main-loop trips / lanes holding a ray   2/3 node steps   4/5 trips of the leaf loop   6/7 refill blocks / lanes refilled
-#ifdef RT_PROFILE_LANES
-__device__ unsigned long long g_lane_stats[8];
-#define RT_LANE_STAT(I, PRED)                                                                      \
-    do {                                                                                           \
-        const unsigned long long act_ = __ballot(true), m_ = __ballot(PRED);                       \
-        if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)act_) - 1u) {                      \
-            atomicAdd(&g_lane_stats[I], 64ull);                                                    \
-            atomicAdd(&g_lane_stats[(I) + 1], (unsigned long long)__popcll(m_));                   \
-        }                                                                                          \
-    } while (0)
-#else
-#define RT_LANE_STAT(I, PRED)
-#endif
-
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 48 // a wave refills from the queue when at least this many lanes are idle
                          // (measured: 8 -> 16.9 ms, 16 -> 15.6, 48 -> 14.7, 64 -> 16.0 per 337 M rays)

@@ -14,7 +14,8 @@ scenes = sys.argv[3:] or ["sphere_scene"]
 _ffi._gpu_lib = None
 _ffi.GPU_LIB_PATH = path
 rt.register_default_images()
-names = ["main loop (lanes holding a ray)", "node step", "leaf loop trip", "refill block (lanes refilled)"]
+names = ["main loop (lanes holding a ray)", "node step", "leaf loop trip", "refill block (lanes refilled)",
+         "random_in_unit_sphere: loop trip", "random_in_unit_sphere: call"]
 for name in scenes:
     scene = rt.Scene.build(name, 16 / 9)
     r = rt.Renderer(0)
@@ -22,7 +23,7 @@ for name in scenes:
     lib = _ffi.load_gpu_library()
     fn = lib.rt_debug_lane_stats
     fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-    out = (ctypes.c_ulonglong * 8)()
+    out = (ctypes.c_ulonglong * 16)()
     p = rt.make_params(1920, 1080, spp, max_depth=50)
     assert fn(out, 1) == 0
     _, _, st = r.render(scene.camera, p)
