@@ -952,7 +952,10 @@ __host__ __device__ inline size_t shade_lds_bytes(uint32_t n_entries, uint32_t n
     return (b + 15u) & ~(size_t)15u;
 }
 template <bool PERLIN_LDS, bool GEN, bool RECTS>
-__global__ __launch_bounds__(256, 4) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
+#ifndef RT_GEN_WAVES
+#define RT_GEN_WAVES 4 // waves per SIMD the depth-0 instantiations are compiled for (5 and 6 measured: no difference)
+#endif
+__global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : 4) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
                                                const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,
                                                float4* __restrict__ rad, ShadeParams tp,
                                                unsigned long long* __restrict__ stats,
