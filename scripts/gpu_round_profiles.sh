@@ -15,6 +15,8 @@ step() { # step <seconds> <command...>
   return 0
 }
 step 120 ./scripts/micro/mul_rate $out/valu_peak.json > $out/mul_rate.txt 2>&1
+# (the micro binaries are built by hand in the container, see the first lines of scripts/micro/*.hip, and travel with the snapshot)
+[ -x ./scripts/micro/latency ] && step 120 ./scripts/micro/latency $out/latency.json > $out/latency.txt 2>&1
 # The PMC passes first: bench.py quotes roofline.traffic / roofline.valu from profiles/round*/, so the files of THIS library
 # have to be in place (in this box's copy of the repo; copy them into the tracked profiles/ afterwards) before the bench lines run.
 prof=$(ls -d profiles/round* | sort -V | tail -1)
