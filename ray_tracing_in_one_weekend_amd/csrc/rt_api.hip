@@ -475,13 +475,37 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     for (size_t k = 0; k < pperm.size(); ++k)
         pperm2[k] = (unsigned short)(pperm[k] | (pperm[(k & ~(size_t)255) + ((k + 1) & 255)] << 8));
     std::vector<ImgRec> imgs(s->n_images);
-    std::vector<float4> texels((size_t)n_texels);
+    // The texel pool: RGBA8 when every component of every image is exactly k/255 (what image::open(..).to_rgb32f() makes of
+    // an 8-bit file, texture.rs:176-177; image_value() divides k by 255 again and gets the same float), float4 otherwise.
+    auto as_u8 = [](float t, uint32_t& k) {
+        if (!(t >= 0.0f && t <= 1.0f)) return false;
+        k = (uint32_t)std::lrintf(t * 255.0f);
+        const float back = (float)k / 255.0f;
+        return k <= 255u && std::memcmp(&back, &t, sizeof(float)) == 0;
+    };
+    bool all_u8 = s->n_images > 0 && !getenv("RTOW_FLOAT_TEXELS");
+    for (uint32_t k = 0; k < s->n_images && all_u8; ++k) {
+        const float* src = s->texels + s->img_offset[k];
+        const size_t nc = (size_t)s->img_w[k] * s->img_h[k] * 3u;
+        uint32_t q;
+        for (size_t c = 0; c < nc && all_u8; ++c) all_u8 = as_u8(src[c], q);
+    }
+    std::vector<float4> texels(all_u8 ? 0 : (size_t)n_texels);
+    std::vector<uint32_t> texels8(all_u8 ? (size_t)n_texels : 0);
     for (uint32_t k = 0; k < s->n_images; ++k) {
         uint64_t off = s->img_offset[k] / 3u;
         imgs[k] = ImgRec{s->img_w[k], s->img_h[k], (uint32_t)off, (uint32_t)(off >> 32)};
         const float* src = s->texels + s->img_offset[k];
         const size_t np = (size_t)s->img_w[k] * s->img_h[k];
-        for (size_t p = 0; p < np; ++p) texels[off + p] = make_float4(src[3 * p], src[3 * p + 1], src[3 * p + 2], 0.0f);
+        for (size_t p = 0; p < np; ++p) {
+            if (all_u8) {
+                uint32_t r = 0, g = 0, b = 0;
+                as_u8(src[3 * p], r), as_u8(src[3 * p + 1], g), as_u8(src[3 * p + 2], b);
+                texels8[off + p] = r | (g << 8) | (b << 16);
+            } else {
+                texels[off + p] = make_float4(src[3 * p], src[3 * p + 1], src[3 * p + 2], 0.0f);
+            }
+        }
     }
 
     // rectangles: device geometry (k, u0, u1, v0), (v1, axis) with (u, v) the uv axes of hitable.rs:262-263 etc.
@@ -686,7 +710,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     if ((rc = upload(ctx, pgeo, &ds.prim_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
         (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
         (rc = upload(ctx, pperm2, &ds.perlin_perm2)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
-        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, pmed, &ds.prim_medium)) || (rc = upload(ctx, med_prims, &ds.med_prims)) || (rc = upload(ctx, med_range, &ds.med_range)) || (rc = upload(ctx, med_xf, &ds.med_xform)) ||
+        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, texels8, &ds.texels8)) || (rc = upload(ctx, pmed, &ds.prim_medium)) || (rc = upload(ctx, med_prims, &ds.med_prims)) || (rc = upload(ctx, med_range, &ds.med_range)) || (rc = upload(ctx, med_xf, &ds.med_xform)) ||
         (rc = upload(ctx, ent_bs, &ds.ent_bs)) || (rc = upload(ctx, entry_ids, &ds.ent_leaf)) ||
         (rc = upload(ctx, med_nid, &ds.med_neg_inv_density)) || (rc = upload(ctx, pxf, &ds.prim_xform)) || (rc = upload(ctx, xparam, &ds.xf_param)) ||
         (rc = upload(ctx, xmeta, &ds.xf_meta)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
@@ -698,6 +722,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     }
     ds.sph_geo = ds.prim_geo;
     ds.rect_geo = ds.prim_geo + s->n_spheres;
+    if (!all_u8) ds.texels8 = nullptr; // (upload() hands out a 16 B allocation even for an empty pool)
     ctx->ds = ds;
     ctx->has_scene = true;
     // k_intersect keeps nodes + geometry + one u16 stack column per lane in LDS when that fits 160 KB;

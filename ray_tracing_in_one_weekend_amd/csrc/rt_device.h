@@ -235,7 +235,9 @@ struct DevScene {
     const float4* perlin_vec;   // [n_perlin*256] xyz_
     const unsigned short* perlin_perm2; // [n_perlin*3*256] pairs perm[i] | perm[(i+1) & 255] << 8 (PerlinTables)
     const ImgRec* imgs;
-    const float4* texels;       // rgb_
+    const float4* texels;       // rgb_ (used when texels8 is NULL)
+    const uint32_t* texels8;    // r | g << 8 | b << 16: every texel of every image is k/255 exactly (any decoded 8-bit image,
+                                // texture.rs:176-177 to_rgb32f), stored as k; else NULL
     // LDS-resident 4-wide BVH over the spheres, built at upload (rt_bvh.h HostBvh4): per node one
     // float4 per box plane over the 4 children (min_x, min_y, min_z, max_x, max_y, max_z) + child ids:
     // id >= 0: inner node, id < 0: sphere ~id, INT_MIN: empty slot
@@ -316,8 +318,15 @@ __device__ inline V3 image_value(const DevScene& sc, uint32_t img, V2 uv, uint32
     uint32_t i = min(sat_u32(u * (float)ir.w), ir.w - 1u);
     uint32_t j = min(sat_u32(v * (float)ir.h), ir.h - 1u);
     uint64_t off = ((uint64_t)ir.offset_hi << 32) | ir.offset_lo;
-    float4 t = sc.texels[off + (uint64_t)j * ir.w + i];
     ++n_fetch;
+    if (sc.texels8) {
+        // 4 B per texel instead of 16: a 128 B line holds 32 texels of the lookup's neighbourhood instead of 8, and the
+        // pools of config 4 are 7 MB instead of 28.  (float)k / 255.0f is the correctly rounded quotient, the very value
+        // the host's to_rgb32f produced.
+        const uint32_t t8 = sc.texels8[off + (uint64_t)j * ir.w + i];
+        return v3((float)(t8 & 255u) / 255.0f, (float)((t8 >> 8) & 255u) / 255.0f, (float)((t8 >> 16) & 255u) / 255.0f);
+    }
+    float4 t = sc.texels[off + (uint64_t)j * ir.w + i];
     return v3(t.x, t.y, t.z);
 }
 // `on` = outward unit normal of the hit sphere, from which rec.uv is derived lazily (hitable.rs:98)

@@ -230,6 +230,35 @@ def test_many_samples_and_uneven_slices(rt, orc, renderer, name, nx, ny):
         assert np.array_equal(im2.view(np.uint32), img.view(np.uint32)), s
 
 
+def test_texel_pool_rgba8_and_float_fallback(rt, orc, renderer, monkeypatch):
+    """An image whose texels are all k/255 (any decoded 8-bit file, texture.rs:176-177) is kept as RGBA8 on the device and
+    (float)k / 255 is taken at the lookup: the same frame, bit for bit, as with the float4 pool (RTOW_FLOAT_TEXELS=1).
+    An image with other values takes the float4 pool.  Both against the oracle."""
+    rng = np.random.default_rng(7)
+    for name, pixels in (("test/eight_bit.img", (rng.integers(0, 256, (32, 64, 3)).astype(np.float32) / np.float32(255.0))),
+                         ("test/float.img", rng.random((32, 64, 3), dtype=np.float32))):
+        rt.register_image(name, pixels)
+        s = rt.Scene.new()
+        f = rt._ffi
+        img = s.image_tex(name)
+        s.sphere((0, 0, -1), 0.5, s.material(f.MAT_LAMBERT, tex0=img), "textured")
+        s.sphere((0, -100.5, -1), 100.0, s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.8, 0.8, 0.0))), "ground")
+        s.sphere((1.1, 0, -1), 0.5, s.material(f.MAT_EMISSION, tex0=img), "lamp")
+        s.set_camera((0, 0.3, 1.5), (0, 0, -1), (0, 1, 0), 50, 2.0)
+        s.finish()
+        p = rt.make_params(128, 64, 16, max_depth=8)
+        renderer.upload(s)
+        img_a, _, st = renderer.render(s.camera, p)
+        ref, _, so = _oracle(orc, s, p)
+        assert st.n_rays == so.n_rays and st.n_texture_fetches == so.n_texture_fetches > 0
+        _compare_frames(orc, s, p, img_a, ref, name)
+        monkeypatch.setenv("RTOW_FLOAT_TEXELS", "1")
+        renderer.upload(s)
+        img_b, _, _ = renderer.render(s.camera, p)
+        monkeypatch.delenv("RTOW_FLOAT_TEXELS")
+        assert np.array_equal(img_a.view(np.uint32), img_b.view(np.uint32)), name
+
+
 def test_render_sharding_is_bit_invariant(rt, renderer):
     scene = rt.Scene.build("sphere_scene", 16 / 9)
     renderer.upload(scene)
