@@ -77,6 +77,7 @@ __device__ __forceinline__ int32_t sat_i32(float f) {
 // [i] += 64 per trip of a wave and [i + 1] += the lanes that were active in it.
 //   k_intersect: 0/1 main-loop trips / lanes holding a ray   2/3 node steps   4/5 trips of the leaf loop   6/7 refill blocks
 //   shading:     8/9 trips of the rejection loop of random_in_unit_sphere   10/11 calls of it (lanes entering)
+//   depth 0:     12/13 trips of the candidate-list test of k_shade<GEN>   14/15 waves at depth 0 / lanes that have a list
 #ifdef RT_PROFILE_LANES
 __device__ unsigned long long g_lane_stats[16];
 #define RT_LANE_STAT(I, PRED)                                                                      \

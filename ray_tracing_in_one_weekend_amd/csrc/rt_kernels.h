@@ -1096,6 +1096,7 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : 4) void k_shade(DevScene 
                     uint4 list = make_uint4(RT_LIST_OVERFLOW, 0u, 0u, 0u);
                     if (fused) list = gpd->lists[pl];
                     const uint32_t n_list = list.x & 0xFFFFu;
+                    RT_LANE_STAT(14, fused && n_list != RT_LIST_OVERFLOW); // waves at depth 0 / lanes with a candidate list
                     if (fused && n_list != RT_LIST_OVERFLOW) {
                         // leaf_test<false> over the listed entries: Sphere::hit roots (hitable.rs:75-91), order-independent accept
                         const float a = length_squared(d);
@@ -1107,6 +1108,7 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : 4) void k_shade(DevScene 
                         for (uint32_t t = 0; t < RT_LIST_MAX; ++t) {
                             float th;
                             const int s = (int)ids[t];
+                            if (t < n_list) RT_LANE_STAT(12, true); // (profiling builds: trips of the list test and lanes in them)
                             if (t < n_list && sphere_root(s_geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th) &&
                                 (th < tbest || (th == tbest && s > hit))) {
                                 tbest = th;

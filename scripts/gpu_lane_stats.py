@@ -15,7 +15,7 @@ _ffi._gpu_lib = None
 _ffi.GPU_LIB_PATH = path
 rt.register_default_images()
 names = ["main loop (lanes holding a ray)", "node step", "leaf loop trip", "refill block (lanes refilled)",
-         "random_in_unit_sphere: loop trip", "random_in_unit_sphere: call"]
+         "random_in_unit_sphere: loop trip", "random_in_unit_sphere: call", "depth-0 list test: trip", "depth-0: wave / lanes with a list"]
 for name in scenes:
     scene = rt.Scene.build(name, 16 / 9)
     r = rt.Renderer(0)
