@@ -136,7 +136,7 @@ struct StepBuffers {
     float2* qhit;
     const uint32_t* cin;
     uint32_t* cout;
-    float4* rad;
+    float* rad;
     unsigned long long* totals;
     const GenParams* gpd;
 };
@@ -775,7 +775,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t npix = (uint32_t)npix64;
     // slice size: few, large slices amortise the short-queue tail of the bounce loop (depths > ~12 hold a few
     // thousand rays) — config 2 measured 99 / 88 / 82 / 79.5 ms per frame with 8 / 4 / 2 / 1 slices.  A ray of
-    // the slice costs 104 B of work buffers (two 40 B queues, 8 B hit record, 16 B radiance slot): up to 640 Mi
+    // the slice costs 100 B of work buffers (two 40 B queues, 8 B hit record, 12 B radiance slot): up to 640 Mi
     // rays (65 GiB of the 288 GB HBM), less when the device has less memory to give.
     uint32_t S = prm->spp_slice;
     if (S == 0) {
@@ -784,7 +784,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             size_t held = ctx->rad.bytes + ctx->qhit.bytes;
             for (const DevBuf& b : ctx->qbuf) held += b.bytes;
-            max_rays = std::min<uint64_t>(max_rays, (uint64_t)((double)(free_b + held) * 0.5 / 104.0));
+            max_rays = std::min<uint64_t>(max_rays, (uint64_t)((double)(free_b + held) * 0.5 / (88.0 + 4.0 * RT_RAD_FLOATS)));
         }
         S = (uint32_t)std::max<uint64_t>(1, max_rays / npix64);
     }
@@ -803,7 +803,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
 
     if ((rc = ensure_queues(ctx, (size_t)nq * cap))) return rc;
     if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
-    if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * sizeof(float4)))) return rc;
+    if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * RT_RAD_FLOATS * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->acc, (size_t)npix * 3 * sizeof(float)))) return rc;
     const size_t counts_bytes = (size_t)(n_depths + 1) * nq * sizeof(uint32_t); // queue sizes [depth][shard]
     if ((rc = ensure(ctx, ctx->counts, counts_bytes))) return rc;
@@ -818,7 +818,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     }
     const Queue Q[2] = {queue_view(ctx, 0), queue_view(ctx, 1)};
     float2* qhit = (float2*)ctx->qhit.p;
-    float4* rad = (float4*)ctx->rad.p;
+    float* rad = (float*)ctx->rad.p;
     float* acc = (float*)ctx->acc.p;
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     unsigned long long* totals = (unsigned long long*)ctx->totals.p; // [0]=tex fetches [1]=bad dirs [2..]=rays per depth
@@ -1043,7 +1043,7 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
     int rc;
     if ((rc = ensure_queues(ctx, (size_t)nq * cap))) return rc;
     if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
-    if ((rc = ensure(ctx, ctx->rad, (size_t)n * sizeof(float4)))) return rc;
+    if ((rc = ensure(ctx, ctx->rad, (size_t)n * RT_RAD_FLOATS * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->counts, (size_t)2 * nq * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->totals, 4 * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->genp, sizeof(GenParams)))) return rc;
@@ -1056,7 +1056,7 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
     RT_HIP(ctx, hipMemcpyAsync(d_d, io->in_d, 3 * (size_t)n * 4, hipMemcpyHostToDevice, st));
     RT_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)2 * nq * sizeof(uint32_t), st));
     RT_HIP(ctx, hipMemsetAsync(ctx->totals.p, 0, 4 * sizeof(unsigned long long), st));
-    RT_HIP(ctx, hipMemsetAsync(ctx->rad.p, 0xFF, (size_t)n * sizeof(float4), st)); // NaN pattern: a survivor has no slot
+    RT_HIP(ctx, hipMemsetAsync(ctx->rad.p, 0xFF, (size_t)n * RT_RAD_FLOATS * sizeof(float), st)); // NaN pattern: a survivor has no slot
     // one "image row" of n pixels, one sample: slot i is pixel i, so its key is path_key(seed 0, pix i, sample 0)
     GenParams gp{};
     gp.nx = n, gp.ny = 1, gp.npix = n, gp.n_rays = n, gp.s0 = 0;
@@ -1067,14 +1067,15 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
     hipLaunchKernelGGL(k_init_counts, dim3((nq + 255u) / 256u), dim3(256), 0, st, gp, counts, (GenParams*)ctx->genp.p);
     hipLaunchKernelGGL(k_debug_fill, dim3((n + 255u) / 256u), dim3(256), 0, st, gp, Q[0], d_o, d_d);
     const bool use_bvh = ctx->use_bvh && !(io->flags & RT_FLAG_BRUTE_FORCE);
-    const StepBuffers sb{Q[0], Q[1], (float2*)ctx->qhit.p, counts, counts + nq, (float4*)ctx->rad.p,
+    const StepBuffers sb{Q[0], Q[1], (float2*)ctx->qhit.p, counts, counts + nq, (float*)ctx->rad.p,
                          (unsigned long long*)ctx->totals.p, (const GenParams*)ctx->genp.p};
     const IntersectParams ip{nq, cap, (int)io->depth, 0u, nq};
     launch_intersect(ctx, st, use_bvh, false, qg.isect_grid, sb, ip);
     const ShadeParams sp{nq, cap, (int)io->depth, 0x7FFFFFFF, 1u, 0u, 0u};
     launch_shade(ctx, st, false, false, nq, sb, sp);
     RT_HIP(ctx, hipGetLastError());
-    std::vector<float4> ha((size_t)nq * cap), hb((size_t)nq * cap), hrad(n);
+    std::vector<float4> ha((size_t)nq * cap), hb((size_t)nq * cap);
+    std::vector<float> hrad((size_t)n * RT_RAD_FLOATS);
     std::vector<float2> hc((size_t)nq * cap), hh((size_t)nq * cap);
     std::vector<uint32_t> hcnt((size_t)2 * nq);
     RT_HIP(ctx, hipMemcpyAsync(hh.data(), ctx->qhit.p, hh.size() * sizeof(float2), hipMemcpyDeviceToHost, st));
@@ -1087,7 +1088,7 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
         RT_HIP(ctx, hipMemcpyAsync(hab.data(), Q[1].a, hab.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
     }
     RT_HIP(ctx, hipMemcpyAsync(hc.data(), Q[1].c, hc.size() * sizeof(float2), hipMemcpyDeviceToHost, st));
-    RT_HIP(ctx, hipMemcpyAsync(hrad.data(), ctx->rad.p, hrad.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(hrad.data(), ctx->rad.p, hrad.size() * sizeof(float), hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipMemcpyAsync(hcnt.data(), counts, hcnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipStreamSynchronize(st));
     for (size_t i = 0; i < hab.size() / 2; ++i) ha[i] = hab[2 * i], hb[i] = hab[2 * i + 1];
@@ -1104,7 +1105,7 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
         io->out_t[i] = hit >= 0 ? hh[pos].x : 0.0f;
         io->out_alive[i] = 0;
         for (int k = 0; k < 3; ++k) io->out_attenuation[3 * (size_t)i + k] = io->out_o[3 * (size_t)i + k] = io->out_d[3 * (size_t)i + k] = 0.0f;
-        io->out_radiance[3 * (size_t)i] = hrad[i].x, io->out_radiance[3 * (size_t)i + 1] = hrad[i].y, io->out_radiance[3 * (size_t)i + 2] = hrad[i].z;
+        for (int c = 0; c < 3; ++c) io->out_radiance[3 * (size_t)i + c] = hrad[RT_RAD_FLOATS * (size_t)i + c];
     }
     size_t n_out = 0;
     for (uint32_t q = 0; q < nq; ++q) {

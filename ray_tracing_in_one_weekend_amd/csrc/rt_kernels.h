@@ -44,6 +44,15 @@ struct Queue {
     float4* b;
     float2* c;
 };
+// Radiance slots: RT_RAD_FLOATS floats per path of the slice, written once (one global_store_dwordx3 when a path ends) and
+// read once by k_resolve.  3: no padding — 4 B less written and 4 B less read per path than the float4 of round 1.
+#ifndef RT_RAD_FLOATS
+#define RT_RAD_FLOATS 3
+#endif
+__device__ __forceinline__ void rad_store(float* __restrict__ rad, size_t slot, float x, float y, float z) {
+    if (RT_RAD_FLOATS == 4) *reinterpret_cast<float4*>(rad + 4u * slot) = make_float4(x, y, z, 0.0f);
+    else *reinterpret_cast<float3*>(rad + 3u * slot) = make_float3(x, y, z);
+}
 
 struct GenParams {
     float cam_origin[3], cam_horizontal[3], cam_vertical[3], cam_llc[3];
@@ -957,7 +966,7 @@ template <bool PERLIN_LDS, bool GEN, bool RECTS>
 #endif
 __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : 4) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
                                                const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,
-                                               float4* __restrict__ rad, ShadeParams tp,
+                                               float* __restrict__ rad, ShadeParams tp,
                                                unsigned long long* __restrict__ stats,
                                                const GenParams* __restrict__ gpd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1143,7 +1152,7 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : 4) void k_shade(DevScene 
                     }
                 }
                 // one 16 B store: beyond depth 0 the slots of a wave are scattered
-                if (!alive) rad[slot] = make_float4(Lr.x, Lr.y, Lr.z, 0.0f);
+                if (!alive) rad_store(rad, slot, Lr.x, Lr.y, Lr.z);
             }
             prefetch(); // (lanes that shaded nothing: beyond the block, or a direction the reference would panic on)
             // wave64 compaction: ballot + prefix popcount; the wave claims its slots from the LDS counter
@@ -1183,16 +1192,17 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : 4) void k_shade(DevScene 
 }
 
 // Sums the slice's samples of each pixel in sample order (main.rs:95-97) onto the running sum.
-__global__ __launch_bounds__(256) void k_resolve(const float4* __restrict__ rad, float* __restrict__ acc, uint32_t npix,
+__global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ rad, float* __restrict__ acc, uint32_t npix,
                                                  uint32_t s_count) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= npix) return;
     float r = acc[3 * (size_t)p], g = acc[3 * (size_t)p + 1], b = acc[3 * (size_t)p + 2];
     for (uint32_t s = 0; s < s_count; ++s) {
-        const float4 src = rad[(size_t)s * npix + p];
-        r += src.x;
-        g += src.y;
-        b += src.z;
+        const float* src = rad + RT_RAD_FLOATS * ((size_t)s * npix + p);
+        const float sx = src[0], sy = src[1], sz = src[2];
+        r += sx;
+        g += sy;
+        b += sz;
     }
     acc[3 * (size_t)p] = r, acc[3 * (size_t)p + 1] = g, acc[3 * (size_t)p + 2] = b;
 }
