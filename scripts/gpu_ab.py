@@ -4,7 +4,12 @@ python scripts/gpu_ab.py <spp> <rounds> libA.so libB.so ...   -> median isect/sh
 
 Position bias: the variant listed FIRST has been seen to read up to 0.5 ms (2-3 %) high on k_shade with two identical
 binaries (gpurun_out/r2/ab_rcp.txt).  List the baseline first AND last, or a copy of the candidate twice, and believe a
-difference only when it exceeds the spread between the identical copies."""
+difference only when it exceeds the spread between the identical copies.
+
+Binary bias: two builds whose k_shade is compiled from identical source (only k_intersect differed, -DRT_REFILL_MIN=40)
+showed k_shade 24.3 / 24.4 ms against 25.0 / 26.1 ms on cornell_box, consistently (gpurun_out/r2/ab_refill_general.txt):
+where a kernel lands in the binary moves it by up to ~3 %.  A same-binary switch (an environment variable read per render,
+as RTOW_FLOAT_TEXELS or RTOW_ONE_STREAM) is the better experiment whenever one is possible."""
 import ctypes
 import os
 import statistics
