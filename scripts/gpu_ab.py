@@ -6,10 +6,11 @@ Position bias: the variant listed FIRST has been seen to read up to 0.5 ms (2-3 
 binaries (gpurun_out/r2/ab_rcp.txt).  List the baseline first AND last, or a copy of the candidate twice, and believe a
 difference only when it exceeds the spread between the identical copies.
 
-Binary bias: two builds whose k_shade is compiled from identical source (only k_intersect differed, -DRT_REFILL_MIN=40)
-showed k_shade 24.3 / 24.4 ms against 25.0 / 26.1 ms on cornell_box, consistently (gpurun_out/r2/ab_refill_general.txt):
-where a kernel lands in the binary moves it by up to ~3 %.  A same-binary switch (an environment variable read per render,
-as RTOW_FLOAT_TEXELS or RTOW_ONE_STREAM) is the better experiment whenever one is possible."""
+Noise floor per scene: on cornell_box the SAME binary read k_shade 24.77 ms first and 25.80 ms last in one run (4 %,
+gpurun_out/r2/ab_align.txt), and two builds with identical k_shade source differed by as much; on sphere_scene identical
+binaries agree to ~1 %.  Judge a k_shade difference on cornell_box or final_scene only against that spread.  A same-binary
+switch (an environment variable read per render, as RTOW_FLOAT_TEXELS or RTOW_ONE_STREAM) alternated several times is the
+better experiment whenever one is possible.  (-falign-loops=64 / 128: no effect on any scene.)"""
 import ctypes
 import os
 import statistics
