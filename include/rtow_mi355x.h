@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 6u
+#define RT_ABI_VERSION 7u
 
 /* error codes */
 #define RT_OK 0
@@ -316,8 +316,17 @@ int rt_get_depth_timings(RtCtx* ctx, uint32_t max_n, float* isect_ms, float* sha
  * n), ONE ncclAllGather over RCCL/xGMI brings the equal-sized band buffers together and the first device restores
  * row order.  librccl is opened at rt_multi_create (dlopen); the single-GPU entry points do not depend on it. */
 typedef struct RtMulti RtMulti;
-/* One RtCtx per listed HIP device + ncclCommInitAll over them.  Replaces main.rs:72-73 for a node. */
+/* One RtCtx per listed HIP device + ncclCommInitAll over them.  Replaces main.rs:72-73 for a node.
+ * N > 1 over RCCL is UNVERIFIED ON HARDWARE until an 8-GPU run of `bench.py --in-library` has been recorded (no box with
+ * more than one GPU has been available to the build); everything around the collective — one host thread per context,
+ * padded band buffers, the de-interleave, the statistics — runs for n = 2, 3 on one GPU through rt_multi_create_ex. */
 int rt_multi_create(const int* device_ids, int n_devices, RtMulti** out);
+/* Same with flags.  RT_MULTI_COPY_GATHER: the all_gather is replaced by device-to-device copies into the same gathered
+ * layout and librccl is not opened at all; a device id may then be listed several times (several contexts rendering
+ * side by side on one GPU).  The test hook that reaches rt_multi_render's n > 1 code on a one-GPU box; frames are
+ * bit-identical to rt_render either way. */
+#define RT_MULTI_COPY_GATHER 1u
+int rt_multi_create_ex(const int* device_ids, int n_devices, uint32_t flags, RtMulti** out);
 void rt_multi_destroy(RtMulti* m);
 int rt_multi_device_count(const RtMulti* m);
 /* Last error text of `m` (or of the calling thread's last failed rt_multi_create if NULL). */

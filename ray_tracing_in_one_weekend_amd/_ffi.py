@@ -96,10 +96,11 @@ class RtBounceIO(C.Structure):
 # void (*RtProgressFn)(void* user, uint32_t spp_done, uint32_t spp_total, const uint8_t* rgb8, uint32_t nx, uint32_t rows)
 RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32)
 
-EXPECTED_ABI = 6  # RT_ABI_VERSION the struct layouts and prototypes below were written for
+MULTI_COPY_GATHER = 1  # RT_MULTI_COPY_GATHER (rt_multi_create_ex)
+EXPECTED_ABI = 7  # RT_ABI_VERSION the struct layouts and prototypes below were written for
 GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
                "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce",
-               "rt_get_depth_timings", "rt_set_progress", "rt_multi_create", "rt_multi_destroy", "rt_multi_device_count",
+               "rt_get_depth_timings", "rt_set_progress", "rt_multi_create", "rt_multi_create_ex", "rt_multi_destroy", "rt_multi_device_count",
                "rt_multi_last_error", "rt_multi_scene_upload", "rt_multi_render", "rt_deinterleave_bands"]
 HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
                 "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
@@ -153,6 +154,8 @@ def load_gpu_library():
     lib.rt_set_progress.restype = C.c_int
     lib.rt_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     lib.rt_multi_create.restype = C.c_int
+    lib.rt_multi_create_ex.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_uint32, C.POINTER(vp)]
+    lib.rt_multi_create_ex.restype = C.c_int
     lib.rt_multi_destroy.argtypes = [vp]
     lib.rt_multi_destroy.restype = None
     lib.rt_multi_device_count.argtypes = [vp]

@@ -323,13 +323,15 @@ def output_file_name(unix_seconds=-1):
 
 class MultiRenderer:
     """The GPUs of one node behind one handle (rt_multi_create): every device renders its row-interleaved bands, RCCL
-    gathers the frame inside the library.  Replaces the thread-pool fan-out of main.rs:72-108 for a node."""
+    gathers the frame inside the library.  Replaces the thread-pool fan-out of main.rs:72-108 for a node.
+    `copy_gather=True` (rt_multi_create_ex, RT_MULTI_COPY_GATHER): device-to-device copies instead of RCCL; `devices` may
+    then repeat an id — several contexts side by side on one GPU, the test hook for the n > 1 code on a one-GPU box."""
 
-    def __init__(self, devices):
+    def __init__(self, devices, copy_gather=False):
         self._lib = _ffi.load_gpu_library()
         self._m = C.c_void_p()
         ids = (C.c_int * len(devices))(*devices)
-        rc = self._lib.rt_multi_create(ids, len(devices), C.byref(self._m))
+        rc = self._lib.rt_multi_create_ex(ids, len(devices), _ffi.MULTI_COPY_GATHER if copy_gather else 0, C.byref(self._m))
         if rc != 0:
             raise RtError(f"rt_multi_create({list(devices)}) failed ({rc}): {self._lib.rt_multi_last_error(None).decode()}")
 

@@ -44,7 +44,10 @@ struct RtCtx {
     DevBuf qbuf[6];   // two queues x (a, b, c)
     DevBuf rad, acc, counts, totals, out_f32, out_u8, dbg, qhit, genp, lists;
     std::vector<hipEvent_t> events;
-    std::vector<hipEvent_t> depth_events;  // RT_FLAG_TIME_DEPTHS: 2 per depth + 1
+    std::vector<hipEvent_t> depth_events;  // RT_FLAG_TIME_DEPTHS: 3 per depth (k_intersect begin, k_shade begin, k_shade end)
+#ifdef RT_WHATIF_REORDER
+    DevBuf qtmp[3];                        // what-if builds: scratch queue of k_whatif_reorder
+#endif
     int timed_depths = 0;
     std::vector<unsigned long long> timed_rays;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -140,7 +143,10 @@ struct StepBuffers {
     unsigned long long* totals;
     const GenParams* gpd;
 };
-bool scene_is_general(const RtCtx* ctx) { return ctx->ds.n_rects > 0 || ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0; }
+bool scene_is_general(const RtCtx* ctx) {
+    static const bool force = getenv("RTOW_FORCE_GENERAL") != nullptr; // experiment knob: the general instantiations on a sphere-only scene
+    return force || ctx->ds.n_rects > 0 || ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0;
+}
 bool scene_perlin_lds(const RtCtx* ctx) { return ctx->ds.n_perlin > 0 && ctx->ds.n_perlin <= RT_PERLIN_LDS_MAX_SETS; }
 
 // closest hit of the shards [ip.q0, ip.q1): the tree instantiation that matches the scene, or the list walk
@@ -309,6 +315,9 @@ void rt_ctx_destroy(RtCtx* ctx) {
     free_buf(ctx->rad), free_buf(ctx->acc), free_buf(ctx->counts), free_buf(ctx->totals);
     free_buf(ctx->out_f32), free_buf(ctx->out_u8), free_buf(ctx->dbg), free_buf(ctx->qhit), free_buf(ctx->genp);
     free_buf(ctx->preview_u8), free_buf(ctx->lists);
+#ifdef RT_WHATIF_REORDER
+    for (auto& b : ctx->qtmp) free_buf(b);
+#endif
     for (auto ev : ctx->events) (void)hipEventDestroy(ev);
     for (auto ev : ctx->depth_events) (void)hipEventDestroy(ev);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -859,7 +868,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const bool time_depths = (prm->flags & RT_FLAG_TIME_DEPTHS) != 0;
     ctx->timed_depths = 0;
     if (time_depths) {
-        while (ctx->depth_events.size() < 2 * (size_t)n_depths + 1) {
+        while (ctx->depth_events.size() < 3 * (size_t)n_depths) {
             hipEvent_t ev;
             RT_HIP(ctx, hipEventCreate(&ev));
             ctx->depth_events.push_back(ev);
@@ -902,17 +911,37 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             const uint32_t* cin = counts + (size_t)depth * nq;
             uint32_t* cout = counts + (size_t)(depth + 1) * nq;
             const bool td = time_depths && sl == 0;
-            if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth], st));
+#ifdef RT_WHATIF_REORDER
+            if (const char* e = getenv("RTOW_WHATIF_REORDER")) { // "oct,nb,dims,order,maxdepth,bx,by,bz,ex,ey,ez": see k_whatif_reorder
+                ReorderParams rp{};
+                int maxd = 0;
+                float ex = 1.f, ey = 1.f, ez = 1.f;
+                if (sscanf(e, "%u,%u,%u,%u,%d,%f,%f,%f,%f,%f,%f", &rp.oct, &rp.nb, &rp.dims, &rp.order, &maxd, &rp.bx, &rp.by, &rp.bz, &ex, &ey, &ez) == 11 &&
+                    depth >= 1 && depth <= maxd && (rp.oct ? 3u : 0u) + rp.dims * rp.nb <= 12u) {
+                    const size_t qbytes = (size_t)nq * cap * sizeof(float4);
+                    if ((rc = ensure(ctx, ctx->qtmp[0], RT_QSTRIDE * qbytes)) || (rc = ensure(ctx, ctx->qtmp[2], qbytes / 2))) return rc;
+                    const float cells = (float)(1u << rp.nb);
+                    rp.cap = cap, rp.sx = cells / ex, rp.sy = cells / ey, rp.sz = cells / ez;
+                    float4* ta = (float4*)ctx->qtmp[0].p;
+                    const Queue tq{ta, ta + 1, (float2*)ctx->qtmp[2].p};
+                    static_assert(RT_QSTRIDE == 2u, "the what-if scratch queue assumes interleaved records");
+                    hipLaunchKernelGGL(k_whatif_reorder, dim3(q1 - q0), dim3(1024), 0, sg, Queue{qi.a + RT_QSTRIDE * (size_t)q0 * cap, qi.b + RT_QSTRIDE * (size_t)q0 * cap, qi.c + (size_t)q0 * cap},
+                                       Queue{tq.a + RT_QSTRIDE * (size_t)q0 * cap, tq.b + RT_QSTRIDE * (size_t)q0 * cap, tq.c + (size_t)q0 * cap}, cin + q0, rp);
+                }
+            }
+#endif
+            if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[3 * (size_t)depth], st));
             const bool gen = fuse_gen && depth == 0;
             ip.depth = depth;
             ip.q0 = q0, ip.q1 = q1;
             const StepBuffers sb{qi, qo, qhit, cin, cout, rad, totals, gpd};
             launch_intersect(ctx, sg, use_bvh, gen, isect_grid_g, sb, ip);
-            if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)depth + 1], st));
+            if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[3 * (size_t)depth + 1], st));
             // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
             const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u,
                                  (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u, q0};
             launch_shade(ctx, sg, gen, !rects && gp.lists != nullptr, q1 - q0, sb, sp);
+            if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[3 * (size_t)depth + 2], st));
             if (grp == 0u) n_trace_launches += 2;
         }
         if (n_groups > 1u) {
@@ -920,7 +949,6 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
         }
         if (time_depths && sl == 0) {
-            RT_HIP(ctx, hipEventRecord(ctx->depth_events[2 * (size_t)n_depths], st));
             ctx->timed_depths = n_depths;
             ctx->timed_rays.assign((size_t)n_depths, 0ull);
             std::vector<uint32_t> hc((size_t)(n_depths + 1) * nq);
@@ -1023,8 +1051,8 @@ int rt_get_depth_timings(RtCtx* ctx, uint32_t max_n, float* isect_ms, float* sha
     const int n = std::min<int>(ctx->timed_depths, (int)max_n);
     for (int d = 0; d < n; ++d) {
         float a_ms = 0.f, b_ms = 0.f;
-        RT_HIP(ctx, hipEventElapsedTime(&a_ms, ctx->depth_events[2 * (size_t)d], ctx->depth_events[2 * (size_t)d + 1]));
-        RT_HIP(ctx, hipEventElapsedTime(&b_ms, ctx->depth_events[2 * (size_t)d + 1], ctx->depth_events[2 * (size_t)d + 2]));
+        RT_HIP(ctx, hipEventElapsedTime(&a_ms, ctx->depth_events[3 * (size_t)d], ctx->depth_events[3 * (size_t)d + 1]));
+        RT_HIP(ctx, hipEventElapsedTime(&b_ms, ctx->depth_events[3 * (size_t)d + 1], ctx->depth_events[3 * (size_t)d + 2]));
         if (isect_ms) isect_ms[d] = a_ms;
         if (shade_ms) shade_ms[d] = b_ms;
         if (rays) rays[d] = ctx->timed_rays[(size_t)d];
@@ -1180,10 +1208,10 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
 #ifdef RT_PROFILE_LANES
 // Diagnostic builds only (not declared in include/rtow_mi355x.h, absent from the product library): the lane statistics
 // of rt_kernels.h, optionally reset after reading.
-extern "C" int rt_debug_lane_stats(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rt::g_lane_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+extern "C" int rt_debug_lane_stats(unsigned long long* out24, int reset) {
+    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(rt::g_lane_stats), RT_LANE_STAT_N * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
-        const unsigned long long zero[16] = {};
+        const unsigned long long zero[RT_LANE_STAT_N] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_lane_stats), zero, sizeof(zero)) != hipSuccess) return -1;
     }
     return 0;

@@ -78,8 +78,11 @@ __device__ __forceinline__ int32_t sat_i32(float f) {
 //   k_intersect: 0/1 main-loop trips / lanes holding a ray   2/3 node steps   4/5 trips of the leaf loop   6/7 refill blocks
 //   shading:     8/9 trips of the rejection loop of random_in_unit_sphere   10/11 calls of it (lanes entering)
 //   depth 0:     12/13 trips of the candidate-list test of k_shade<GEN>   14/15 waves at depth 0 / lanes that have a list
+//   textures:    16/17 waves entering the Perlin turbulence (texture.rs:115-124) / lanes evaluating it
+//   shading:     18/19 64-ray segments shaded by k_shade / lanes holding a ray in them
 #ifdef RT_PROFILE_LANES
-__device__ unsigned long long g_lane_stats[16];
+#define RT_LANE_STAT_N 24
+__device__ unsigned long long g_lane_stats[RT_LANE_STAT_N];
 #define RT_LANE_STAT(I, PRED)                                                                      \
     do {                                                                                           \
         const unsigned long long act_ = __ballot(true), m_ = __ballot(PRED);                       \
@@ -366,6 +369,7 @@ __device__ inline V3 texture_value_inline(const DevScene& sc, const PerlinTables
         return v3(tr.c1r, tr.c1g, tr.c1b);
     }
     case 2: { // PerlinTex texture.rs:164-168
+        RT_LANE_STAT(16, true);
         float s = sinf(10.0f * perlin_turb(pt, taux, p) + scale * p.z);
         return (s + 1.0f) * 0.5f * splat(1.0f);
     }

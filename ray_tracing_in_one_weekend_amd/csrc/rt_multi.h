@@ -58,6 +58,8 @@ struct RtMulti {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::vector<ncclComm_t> comms;
+    bool copy_gather = false; // RT_MULTI_COPY_GATHER: device-to-device copies instead of ncclAllGather, no RCCL at all
+    std::vector<hipEvent_t> gather_done; // copy_gather: context i's copies have been enqueued up to this event
     // per device: band buffer and gathered buffer; first device: full frame
     std::vector<DevBuf> local, gathered;
     DevBuf full_f32, full_u8;
@@ -90,16 +92,24 @@ void rt_multi_destroy(RtMulti* m) {
     }
     for (ncclComm_t c : m->comms)
         if (c && m->CommDestroy) (void)m->CommDestroy(c);
+    for (size_t i = 0; i < m->gather_done.size(); ++i) {
+        (void)hipSetDevice(m->devices[i]);
+        if (m->gather_done[i]) (void)hipEventDestroy(m->gather_done[i]);
+    }
     for (RtCtx* c : m->ctx) rt_ctx_destroy(c);
     if (m->lib) dlclose(m->lib);
     delete m;
 }
 
-int rt_multi_create(const int* device_ids, int n_devices, RtMulti** out) {
+int rt_multi_create(const int* device_ids, int n_devices, RtMulti** out) { return rt_multi_create_ex(device_ids, n_devices, 0u, out); }
+
+int rt_multi_create_ex(const int* device_ids, int n_devices, uint32_t flags, RtMulti** out) {
     if (!out) return multi_fail(nullptr, RT_ERR_INVALID, "rt_multi_create: out is NULL");
     *out = nullptr;
     if (!device_ids || n_devices <= 0) return multi_fail(nullptr, RT_ERR_INVALID, "rt_multi_create: need at least one device id");
-    for (int i = 0; i < n_devices; ++i)
+    if (flags & ~RT_MULTI_COPY_GATHER) return multi_fail(nullptr, RT_ERR_INVALID, "rt_multi_create_ex: unknown flag");
+    const bool copy_gather = (flags & RT_MULTI_COPY_GATHER) != 0u;
+    for (int i = 0; i < n_devices && !copy_gather; ++i) // (an RCCL communicator cannot hold one device twice)
         for (int k = 0; k < i; ++k)
             if (device_ids[i] == device_ids[k]) return multi_fail(nullptr, RT_ERR_INVALID, "rt_multi_create: a device id is listed twice");
     RtMulti* m = new (std::nothrow) RtMulti();
@@ -116,6 +126,17 @@ int rt_multi_create(const int* device_ids, int n_devices, RtMulti** out) {
         m->devices.push_back(device_ids[i]);
     }
     m->local.resize(n_devices), m->gathered.resize(n_devices);
+    if (copy_gather) { // no RCCL: the gather is n*n device-to-device copies ordered by one event per context
+        m->copy_gather = true;
+        m->gather_done.assign(n_devices, nullptr);
+        for (int i = 0; i < n_devices; ++i) {
+            hipError_t e = hipSetDevice(device_ids[i]);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&m->gather_done[i], hipEventDisableTiming);
+            if (e != hipSuccess) return bail(RT_ERR_DEVICE, std::string("rt_multi_create_ex: hipEventCreate: ") + hipGetErrorString(e));
+        }
+        *out = m;
+        return RT_OK;
+    }
     {   // the RCCL that belongs to the HIP runtime this library is bound to: a process may hold two ROCm stacks (PyTorch
         // wheels bundle their own), and an RCCL from the other one brings up a second HSA runtime that sees no device
         std::vector<std::string> names;
@@ -215,12 +236,31 @@ int rt_multi_render(RtMulti* m, const RtCamera* cam, const RtParams* params, flo
     for (uint32_t i = 0; i < n; ++i)
         if (rcs[i]) return multi_fail(m, rcs[i], std::string("device ") + std::to_string(m->devices[i]) + ": " + rt_last_error(m->ctx[i]));
     // ---- the one exchange step: all_gather of the band buffers on the devices' own streams ------------------
-    ncclResult_t nr = m->GroupStart();
-    for (uint32_t i = 0; i < n && nr == ncclSuccess; ++i)
-        nr = m->AllGather(m->local[i].p, m->gathered[i].p, band_floats, ncclFloat, m->comms[i], m->ctx[i]->stream);
-    const ncclResult_t ne = m->GroupEnd();
-    if (nr == ncclSuccess) nr = ne;
-    if (nr != ncclSuccess) return multi_fail(m, RT_ERR_DEVICE, std::string("rt_multi_render: ncclAllGather: ") + m->GetErrorString(nr));
+    if (m->copy_gather) {
+        // the same data movement as the all_gather — context i's band buffer into slot i of EVERY gathered buffer — as plain
+        // device-to-device copies on context i's stream; every stream then waits for all the others' copies
+        hipError_t e = hipSuccess;
+        for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
+            e = hipSetDevice(m->devices[i]);
+            for (uint32_t k = 0; k < n && e == hipSuccess; ++k)
+                e = hipMemcpyAsync((float*)m->gathered[k].p + (size_t)i * band_floats, m->local[i].p, band_floats * sizeof(float),
+                                   hipMemcpyDeviceToDevice, m->ctx[i]->stream);
+            if (e == hipSuccess) e = hipEventRecord(m->gather_done[i], m->ctx[i]->stream);
+        }
+        for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
+            e = hipSetDevice(m->devices[i]);
+            for (uint32_t k = 0; k < n && e == hipSuccess; ++k)
+                if (k != i) e = hipStreamWaitEvent(m->ctx[i]->stream, m->gather_done[k], 0);
+        }
+        if (e != hipSuccess) return multi_fail(m, RT_ERR_DEVICE, std::string("rt_multi_render: copy gather: ") + hipGetErrorString(e));
+    } else {
+        ncclResult_t nr = m->GroupStart();
+        for (uint32_t i = 0; i < n && nr == ncclSuccess; ++i)
+            nr = m->AllGather(m->local[i].p, m->gathered[i].p, band_floats, ncclFloat, m->comms[i], m->ctx[i]->stream);
+        const ncclResult_t ne = m->GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return multi_fail(m, RT_ERR_DEVICE, std::string("rt_multi_render: ncclAllGather: ") + m->GetErrorString(nr));
+    }
     // ---- row order + quantisation on the first device, then to the host --------------------------------------
     RtCtx* c0 = m->ctx[0];
     if (hipSetDevice(m->devices[0]) != hipSuccess) return multi_fail(m, RT_ERR_DEVICE, "hipSetDevice failed");

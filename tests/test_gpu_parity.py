@@ -482,6 +482,70 @@ def test_in_library_multi_gpu_entry_points(rt, renderer):
             assert hip.hipFree(b) == 0
 
 
+def test_rt_multi_render_n_contexts_on_one_gpu(rt, renderer):
+    """rt_multi_render's N > 1 code on a one-GPU box (rt_multi_create_ex, RT_MULTI_COPY_GATHER): n contexts share
+    device 0, ONE HOST THREAD PER CONTEXT renders its row-interleaved bands at the same time (main.rs:72-108 is the
+    fan-out this replaces), the all_gather is n*n device-to-device copies into the same gathered layout, then the padded
+    band buffers (181 rows: shards differ in size) go through k_bands_to_image and the statistics are reduced.  Frames
+    and ray counts are those of rt_render, bit for bit, for n = 2 and 3 — a general scene and the sphere-only one, so
+    that both families of kernel instantiations (and their process-global LDS attribute) run from several threads."""
+    for name, nx, ny, aspect in (("sphere_scene", 320, 181, 16 / 9), ("cornell_box", 181, 181, 1.0)):
+        scene = rt.Scene.build(name, aspect)
+        renderer.upload(scene)
+        p = rt.make_params(nx, ny, 6, max_depth=20, seed=95)
+        ref, ref8, st = renderer.render(scene.camera, p, want_rgb8=True)
+        for n in (2, 3):
+            m = rt.MultiRenderer([0] * n, copy_gather=True)
+            assert m.n_devices == n
+            m.upload(scene)
+            for _ in range(2):  # the second call reuses every buffer
+                img, rgb8, sm = m.render(scene.camera, p, want_rgb8=True)
+                assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (name, n)
+                assert np.array_equal(rgb8, ref8)
+                assert sm.n_rays == st.n_rays and sm.n_paths == st.n_paths and list(sm.rays_per_depth) == list(st.rays_per_depth)
+                assert sm.n_texture_fetches == st.n_texture_fetches and sm.n_bad_dir == 0
+            m.close()
+    import ctypes
+    lib, handle = rt._ffi.load_gpu_library(), ctypes.c_void_p()
+    assert lib.rt_multi_create_ex((ctypes.c_int * 1)(0), 1, 0x80, ctypes.byref(handle)) == -1 and not handle  # RT_ERR_INVALID
+    assert b"unknown flag" in lib.rt_multi_last_error(None)
+
+
+def test_two_host_threads_render_on_two_contexts_at_once(rt):
+    """Two contexts on one device, each driven by its own Python thread (ctypes releases the GIL during the call), eight
+    renders each, different scenes so that different kernel instantiations are launched side by side: every frame equals
+    the one the same context renders alone.  Covers what a multi-threaded host relies on: per-context streams, events and
+    error strings, and kernel attributes that are set once per process."""
+    import threading
+    jobs = []
+    for name, nx, ny, aspect in (("sphere_scene", 256, 144, 16 / 9), ("final_scene", 160, 160, 1.0)):
+        scene = rt.Scene.build(name, aspect)
+        r = rt.Renderer(0)
+        r.upload(scene)
+        p = rt.make_params(nx, ny, 4, max_depth=12, seed=7)
+        ref, _, st = r.render(scene.camera, p)
+        jobs.append((r, scene, p, ref, st.n_rays))
+    errors = []
+
+    def work(job):
+        r, scene, p, ref, n_rays = job
+        try:
+            for _ in range(8):
+                img, _, st = r.render(scene.camera, p)
+                assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and st.n_rays == n_rays
+        except Exception as e:  # noqa: BLE001 (reported below, on the main thread)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for r, *_ in jobs:
+        r.close()
+
+
 def test_scene_too_large_for_the_lds_bvh_uses_the_list_walk(rt, orc, renderer):
     """3000 spheres: the BVH (2999 nodes x 64 B) no longer fits LDS, so closest hit falls back to the
     tiled list walk (two LDS tiles); results still equal the oracle's."""
