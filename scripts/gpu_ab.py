@@ -1,5 +1,5 @@
 """Interleaved A/B of library builds in ONE process on ONE device (cdna guide rule 24):
-python scripts/gpu_ab.py <spp> <rounds> libA.so libB.so ...   -> median isect/shade/total ms per variant
+python scripts/gpu_ab.py <spp> <rounds> libA.so libB.so[@ENV=VALUE] ...   -> median isect/shade/total ms per variant
 (RTOW_SCENE=name picks the scene, RTOW_AB_DEPTHS=N adds the per-depth split of the first N depths)
 
 Position bias: the variant listed FIRST has been seen to read up to 0.5 ms (2-3 %) high on k_shade with two identical
@@ -25,11 +25,18 @@ libs = sys.argv[3:]
 rt.register_default_images()
 scene = rt.Scene.build(os.environ.get("RTOW_SCENE", "sphere_scene"), 16 / 9)
 rends = []
-for path in libs:
+for k, spec in enumerate(libs):  # "lib.so" or "lib.so@ENV=VALUE[,ENV2=VALUE2]": variables set while this variant's scene is uploaded
+    path, _, envs = spec.partition("@")
+    libs[k] = os.path.basename(path) + ("@" + envs if envs else "")
     _ffi._gpu_lib = None
     _ffi.GPU_LIB_PATH = path
+    kv = [e.split("=", 1) for e in envs.split(",") if e]
+    for name, val in kv:
+        os.environ[name] = val
     r = rt.Renderer(0)
     r.upload(scene)
+    for name, _ in kv:
+        os.environ.pop(name, None)
     rends.append(r)
 p = rt.make_params(1920, 1080, spp, max_depth=50, flags=rt._ffi.FLAG_TIME_DEPTHS)
 res = {i: [] for i in range(len(libs))}
