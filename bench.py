@@ -47,38 +47,43 @@ CONFIGS = {  # BASELINE.json configs[1..4]
 }
 
 
-def _latest_profile(pattern, workload_key):
-    """Newest profiles/round*/<pattern> whose bench_config.workload is this run's workload."""
+def _latest_profile(pattern, workload_key, build_id):
+    """Newest profiles/round*/<pattern> of this run's workload AND of the kernels that are running: a profile records the
+    rt_build_id() of the library it was taken on (hash of the device sources + flags); one taken on other kernels is refused.
+    Returns (path, json) or (None, reason)."""
     import glob
-    best = None
+    best, stale = None, None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", pattern))):
         try:
             t = json.load(open(p))
         except (OSError, ValueError):
             continue
-        if (t.get("bench_config") or {}).get("workload") == workload_key:
-            best = (p, t)
-    return best
+        if (t.get("bench_config") or {}).get("workload") != workload_key:
+            continue
+        if t.get("library_build_id") != build_id:
+            stale = f"{os.path.relpath(p, ROOT)} was taken on build {t.get('library_build_id')}, this library is {build_id}"
+            continue
+        best = (p, t)
+    return best if best else (None, stale)
 
 
-def pmc_traffic(workload_key):
-    """HBM bytes per trace-step launch from the committed PMC pass of this same command
-    (scripts/collect_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections).
-    bench.py cannot profile itself, so the number comes from profiles/; null when absent or stale."""
-    best = _latest_profile("traffic*.json", workload_key)
-    if not best:
-        return None, None
-    p, t = best
+def pmc_traffic(workload_key, build_id):
+    """HBM bytes per trace-step launch from the committed PMC pass of this same command on this same build
+    (scripts/collect_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, corrections calibrated in
+    profiles/round3/fetch_calibration.json).  bench.py cannot profile itself, so the number comes from profiles/;
+    null (with the reason as the source) when there is none for these kernels."""
+    p, t = _latest_profile("traffic*.json", workload_key, build_id)
+    if not p:
+        return None, t
     return t["trace_step_bytes_per_launch"], os.path.relpath(p, ROOT)
 
 
-def pmc_valu(workload_key):
-    """VALU issue fraction / lane utilisation of the trace kernels from the committed PMC pass of this same command
-    (scripts/collect_valu.py) against the MEASURED issue rate of scripts/micro/mul_rate.hip; None when absent."""
-    best = _latest_profile("valu*.json", workload_key)
-    if not best:
+def pmc_valu(workload_key, build_id):
+    """VALU issue fraction / lane utilisation of the trace kernels from the committed PMC pass of this same command on this
+    same build (scripts/collect_valu.py) against the MEASURED issue rate of scripts/micro/mul_rate.hip; None when absent."""
+    p, t = _latest_profile("valu*.json", workload_key, build_id)
+    if not p:
         return None
-    p, t = best
     out = {k: {"issue_frac": round(v["issue_frac"], 4), "lane_util": round(v["lane_util"], 4)} for k, v in t["kernels"].items()}
     out["peak_wave_insts_per_s"] = t.get("peak_wave_insts_per_s")
     out["source"] = os.path.relpath(p, ROOT)
@@ -123,6 +128,56 @@ def cpu_baseline(rt, scene, name, nx, ny, max_depth, budget_s=15.0):
                       f"(oracle stream mode: per-column xoshiro256++, recursive estimator, BVH)"}
 
 
+def in_library_check(rt, scene, renderer, frame, n_dev, timeout_s=150.0):
+    """The one-process multi-GPU entry point (rt_multi_create over devices 0..n_dev-1: one host thread per device, RCCL
+    ncclAllGather INSIDE the library, de-interleave on device 0) next to the torch.distributed path the bench line times:
+    a small frame must equal this process's own rt_render bit for bit (f32 and RGB8, ray counts), then the bench frame is
+    rendered once through it for a throughput figure.  Runs in a thread with a deadline: a hang in a collective that has never
+    executed with n > 1 must not cost the bench line."""
+    import threading
+
+    import numpy as np
+    res = {"devices": n_dev, "ok": False, "what": "rt_multi_render: RCCL ncclCommInitAll + ncclAllGather inside librtow_mi355x.so"}
+
+    def work():
+        try:
+            nx, ny, spp, max_depth = frame
+            small = rt.make_params(480, 270, 16, max_depth=max_depth, seed=95)
+            ref, ref8, st = renderer.render(scene.camera, small, want_rgb8=True)
+            m = rt.MultiRenderer(list(range(n_dev)))
+            m.upload(scene)
+            img, rgb8, sm = m.render(scene.camera, small, want_rgb8=True)
+            res["bit_identical"] = bool(np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and np.array_equal(rgb8, ref8))
+            res["rays_equal"] = bool(sm.n_rays == st.n_rays and list(sm.rays_per_depth) == list(st.rays_per_depth))
+            full = rt.make_params(nx, ny, spp, max_depth=max_depth, seed=95)
+            m.render(scene.camera, full)  # warm-up: buffers
+            t0 = time.perf_counter()
+            _, _, sf = m.render(scene.camera, full)
+            dt = time.perf_counter() - t0
+            res["frame"] = f"{nx}x{ny}, {spp} spp to host memory"
+            res["value_host_inclusive"] = round(sf.n_rays / dt / 1e6, 3)
+            res["ms_per_frame"] = round(dt * 1e3, 3)
+            m.close()
+            res["ok"] = res["bit_identical"] and res["rays_equal"]
+        except Exception as e:  # noqa: BLE001 (reported in the JSON line)
+            res["error"] = repr(e)[:400]
+
+    # RCCL prints a version banner on stdout when a communicator is created: this process's stdout carries ONE JSON line, so
+    # file descriptor 1 points at stderr while the check runs
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    sys.stdout.flush()
+    os.dup2(saved, 1)
+    os.close(saved)
+    if th.is_alive():
+        res["error"], res["hung"] = f"no result after {timeout_s:.0f} s", True
+    return res
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -155,6 +210,9 @@ def main():
     ap.add_argument("--spp-slice", type=int, default=0)
     ap.add_argument("--band", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-library", action="store_true",
+                    help="after the timed region, rank 0 also renders through rt_multi_render (one process, all --gpus devices, the RCCL "
+                         "gather inside the library) and reports bit-identity with rt_render; always on when --gpus > 1")
     ap.add_argument("--launcher-check", action="store_true",
                     help="rendezvous, world-size assertion and one framebuffer gather of a synthetic band buffer; no rendering "
                          "(the CPU test of the multi-rank launch path: RTOW_DIST_BACKEND=gloo, no GPU needed)")
@@ -180,20 +238,32 @@ def main():
 
     if args.launcher_check:
         from ray_tracing_in_one_weekend_amd import shard
+        # the gather runs over RCCL only when the backend is nccl AND every rank has a device of its own; otherwise gloo on
+        # host tensors (NCCL has no CPU backend), and the line says so
+        on_rccl = backend == "nccl" and torch.cuda.is_available() and torch.cuda.device_count() >= world
+        dev = torch.device("cpu")
+        if on_rccl:
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
         if world > 1:
-            dist.init_process_group(backend="gloo" if backend != "nccl" or not torch.cuda.is_available() else "nccl")
+            if on_rccl:
+                dist.init_process_group(backend="nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend="gloo")
             assert dist.get_world_size() == n_req
         ny, nx = 64, 16
         rows = shard.shard_rows(ny, args.band, world, rank)
-        local = torch.zeros((len(rows), nx, 3), dtype=torch.float32)
-        local[:, :, 0] = torch.as_tensor(rows, dtype=torch.float32)[:, None]  # every pixel carries its image row
+        local = torch.zeros((len(rows), nx, 3), dtype=torch.float32, device=dev)
+        local[:, :, 0] = torch.as_tensor(rows, dtype=torch.float32, device=dev)[:, None]  # every pixel carries its image row
         full = shard.gather_framebuffer(local, ny, args.band) if world > 1 else local
-        ok = bool((full[:, 0, 0] == torch.arange(ny, dtype=torch.float32)).all())
+        ok = bool((full[:, 0, 0].cpu() == torch.arange(ny, dtype=torch.float32)).all())
         if world > 1:
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"launcher_check": ok, "n_gpus": world, "rccl_ranks": world if backend == "nccl" else 0,
-                              "backend": backend, "gather": gather_name}))
+            ran = "nccl" if (on_rccl and world > 1) else "gloo"
+            print(json.dumps({"launcher_check": ok, "n_gpus": world, "rccl_ranks": world if ran == "nccl" else 0,
+                              "backend": ran, "gather": "RCCL all_gather over xGMI" if ran == "nccl" else
+                              "gloo all_gather through host memory (rehearsal)"}))
         if world > 1:
             dist.destroy_process_group()
         sys.exit(0 if ok else 1)
@@ -278,6 +348,12 @@ def main():
     else:
         elapsed_max, rays_total = elapsed, float(rays_local)
 
+    if world > 1:  # every collective of the measurement is behind us: the other ranks leave and free their GPUs
+        dist.barrier()
+        dist.destroy_process_group()
+    in_library = None
+    if rank == 0 and (args.in_library or world > 1):
+        in_library = in_library_check(rt, scene, renderer, (nx, ny, spp_total, args.max_depth), world)
     if rank == 0:
         s0 = stats[-1]
         trace_s = sum(s.seconds_trace for s in stats)
@@ -288,9 +364,11 @@ def main():
         workload = (f"config {args.config}: {cfg['what']} {nx}x{ny}, {per_gpu}, max_depth {args.max_depth}, "
                     f"seed 95, counter RNG; rows sharded in bands of {args.band} over {world} GPU(s)"
                     + (f", {gather_name} of the f32 framebuffer per step" if world > 1 else ""))
-        traffic, traffic_src = pmc_traffic(workload)
+        build_id = renderer.build_id
+        traffic, traffic_src = pmc_traffic(workload, build_id)
         out = {
-            "metric": "Mray/s (primary+secondary) at 1920x1080/256spp",
+            # BASELINE.json's metric is quoted on config 2; the other configs carry their own frame in the label
+            "metric": f"Mray/s (primary+secondary) at {nx}x{ny}/{spp_total}spp",
             "value": round(rays_total / elapsed_max / 1e6, 3),
             "unit": "Mray/s",
             "n_gpus": world,
@@ -312,7 +390,7 @@ def main():
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "valu": pmc_valu(workload),
+                         "valu": pmc_valu(workload, build_id),
                          "bytes_per_launch": round(trace_bytes / max(launches, 1), 1),
                          "avg_launch_us": round(trace_s / max(launches, 1) * 1e6, 3),
                          "launches": launches,
@@ -320,18 +398,32 @@ def main():
                                  "streams, so rocprof lists twice as many dispatches of about this duration); algorithmic bytes = "
                                  "48 B/ray read + 48 B/surviving ray written + 12 B/path radiance + 12 B/ImageTex fetch (SURVEY.md 8(d): "
                                  "96 B/ray + 24 B/path + 12 B/fetch over gen+trace+resolve); time = HIP events around the trace launches "
-                                 "of every slice on the launch stream; traffic = PMC FETCH_SIZE*2 + WRITE_SIZE of both kernels per launch"},
+                                 "of every slice on the launch stream; traffic = PMC FETCH_SIZE*2 + WRITE_SIZE of both kernels per launch "
+                                 "(x2 calibrated for streams AND gathers: profiles/round3/fetch_calibration.json).  The algorithmic figure "
+                                 "follows the SURVEY 8(d) CONVENTION of a 48 B ray record; the records this layout moves are 40 B + an 8 B "
+                                 "hit record between the kernels, i.e. the same 48 B per ray read and 40 B per survivor written"},
+            "library_build_id": build_id,
             "whole_path": {"bytes_algorithmic_per_step": int(s0.bytes_algorithmic),
                            "device_seconds_per_step": round(s0.seconds_device, 6),
                            "hbm_frac": round(s0.bytes_algorithmic / max(s0.seconds_device, 1e-12) / 1e9 / HBM_PEAK_GBPS, 5)},
         }
+        if world == 1:
+            # the same frame handed to the HOST as the reference's output is (f32 frame + flipped RGB8 through rt_render:
+            # the D2H copies included), never `value`: reported beside it
+            th0 = time.perf_counter()
+            host_rays = 0
+            for _ in range(max(1, min(args.steps, 3))):
+                _, _, sth = renderer.render(scene.camera, params, want_rgb8=True)
+                host_rays += sth.n_rays
+            out["value_host_inclusive"] = round(host_rays / (time.perf_counter() - th0) / 1e6, 3)
+        if args.in_library or world > 1:
+            out["in_library"] = in_library
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rt, scene, cfg["scene"], nx, ny, args.max_depth)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 2)
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+        if in_library and in_library.get("hung"):
+            os._exit(0)  # the line is out; do not wait for a wedged collective at interpreter exit
     renderer.close()
 
 

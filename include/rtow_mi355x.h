@@ -253,6 +253,9 @@ typedef struct RtCtx RtCtx;
 
 /* -- lifecycle ------------------------------------------------------------------------ */
 uint32_t rt_abi_version(void);
+/* 16 hex digits over the device sources and compiler flags the library was built from ("unknown" for a hand-made build).
+ * Measurement records (profiles/) carry it so that a number is never quoted for kernels other than the ones it was taken on. */
+const char* rt_build_id(void);
 /* Creates a context on HIP device `device_id`.  Replaces main.rs:72-73 (thread pool setup). */
 int rt_ctx_create(int device_id, RtCtx** out_ctx);
 void rt_ctx_destroy(RtCtx* ctx);

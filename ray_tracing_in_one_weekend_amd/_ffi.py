@@ -98,7 +98,7 @@ RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C
 
 MULTI_COPY_GATHER = 1  # RT_MULTI_COPY_GATHER (rt_multi_create_ex)
 EXPECTED_ABI = 7  # RT_ABI_VERSION the struct layouts and prototypes below were written for
-GPU_SYMBOLS = ["rt_abi_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
+GPU_SYMBOLS = ["rt_abi_version", "rt_build_id", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
                "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce",
                "rt_get_depth_timings", "rt_set_progress", "rt_multi_create", "rt_multi_create_ex", "rt_multi_destroy", "rt_multi_device_count",
                "rt_multi_last_error", "rt_multi_scene_upload", "rt_multi_render", "rt_deinterleave_bands"]
@@ -130,6 +130,7 @@ def load_gpu_library():
     if lib.rt_abi_version() != EXPECTED_ABI:  # a stale .so would be read with the wrong struct layouts
         raise GpuLibraryMissing(f"{GPU_LIB_PATH} has ABI version {lib.rt_abi_version()}, this package expects {EXPECTED_ABI}: "
                                 "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
+    lib.rt_build_id.restype = C.c_char_p
     lib.rt_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.rt_ctx_create.restype = C.c_int
     lib.rt_ctx_destroy.argtypes = [vp]

@@ -201,6 +201,11 @@ class Renderer:
     def _raise(self, what, rc):
         raise RtError(f"{what} failed ({rc}): {self._lib.rt_last_error(self._ctx).decode()}")
 
+    @property
+    def build_id(self):
+        """rt_build_id(): hash of the device sources + compiler flags the loaded library was built from."""
+        return self._lib.rt_build_id().decode()
+
     def upload(self, scene):
         ptr = scene.flat_ptr if isinstance(scene, Scene) else C.pointer(scene)
         rc = self._lib.rt_scene_upload(self._ctx, ptr)

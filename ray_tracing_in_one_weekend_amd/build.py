@@ -1,5 +1,6 @@
 """Build recipes for the native libraries (in-tree, so the built .so travels with the repo
 snapshot to the GPU box).  hipcc cross-compiles gfx950 without a GPU."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -40,15 +41,28 @@ def build_gpu_debug_library(out=None):
     return out
 
 
+def gpu_sources():
+    csrc = os.path.join(PKG_DIR, "csrc")
+    return [os.path.join(csrc, f) for f in ("rt_api.hip", "rt_kernels.h", "rt_device.h", "rt_bvh.h", "rt_multi.h")] + \
+           [os.path.join(ROOT, "include", "rtow_mi355x.h")]
+
+
+def gpu_build_id():
+    """16 hex digits over the device sources and the compiler flags: what rt_build_id() of a library built from this tree returns.
+    Profiles under profiles/ record it, and bench.py refuses to quote a profile taken on other kernels."""
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for s in gpu_sources():
+        h.update(open(s, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_gpu_library(force=False):
     """hipcc --offload-arch=gfx950: HIP kernels + C-ABI -> librtow_mi355x.so"""
-    csrc = os.path.join(PKG_DIR, "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("rt_api.hip", "rt_kernels.h", "rt_device.h", "rt_bvh.h", "rt_multi.h")]
-    srcs.append(os.path.join(ROOT, "include", "rtow_mi355x.h"))
+    srcs = gpu_sources()
     out = os.path.join(PKG_DIR, "librtow_mi355x.so")
     if force or _newer(out, srcs):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        _run([hipcc] + HIPCC_FLAGS + ["-o", out, srcs[0]])
+        _run([hipcc] + HIPCC_FLAGS + [f'-DRT_BUILD_ID="{gpu_build_id()}"', "-o", out, srcs[0]])
     return out
 
 
@@ -63,15 +77,6 @@ def build_host_library(force=False):
     return out
 
 
-def build_oracle(force=False):
-    """g++: CPU restatement used by tests / smoke / bench cpu_baseline only."""
-    odir = os.path.join(ROOT, "oracle")
-    out = os.path.join(odir, "liboracle.so")
-    srcs = [os.path.join(odir, "oracle.cpp"), os.path.join(ROOT, "include", "rtow_mi355x.h")]
-    if force or _newer(out, srcs):
-        _run(["make", "-C", odir, "-B" if force else "-s", "liboracle.so"])
-    return out
-
-
 def build_all(force=False):
-    return [build_gpu_library(force), build_host_library(force), build_oracle(force)]
+    """The product libraries only.  The CPU oracle is test infrastructure and builds from its own directory (oracle/build.py)."""
+    return [build_gpu_library(force), build_host_library(force)]

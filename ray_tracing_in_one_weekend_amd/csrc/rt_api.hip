@@ -240,6 +240,11 @@ extern "C" {
 
 uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
 
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char* rt_build_id(void) { return RT_BUILD_ID; }
+
 const char* rt_last_error(const RtCtx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int rt_ctx_create(int device_id, RtCtx** out_ctx) {
@@ -332,10 +337,11 @@ void rt_ctx_destroy(RtCtx* ctx) {
 uint32_t rt_shard_rows(uint32_t ny, uint32_t shard_band, uint32_t shard_count, uint32_t shard_id) {
     if (shard_count <= 1) return ny;
     if (shard_band == 0) shard_band = 1;
-    uint32_t n = 0;
-    for (uint32_t j = 0; j < ny; ++j)
-        if ((j / shard_band) % shard_count == shard_id) ++n;
-    return n;
+    if (shard_id >= shard_count) return 0;
+    // rows j with (j / band) % count == id: `band` rows out of every cycle of band * count, plus what the last partial cycle holds
+    const uint64_t cycle = (uint64_t)shard_band * shard_count;
+    const uint64_t rem = ny % cycle, lo = (uint64_t)shard_id * shard_band;
+    return (uint32_t)((ny / cycle) * shard_band + (rem > lo ? std::min<uint64_t>(rem - lo, shard_band) : 0u));
 }
 
 uint32_t rt_shard_row_to_image_row(uint32_t local_row, uint32_t shard_band, uint32_t shard_count, uint32_t shard_id) {
@@ -761,6 +767,10 @@ static int check_params(RtCtx* ctx, const RtCamera* cam, const RtParams* p) {
     if (p->max_depth < 0 || p->max_depth > 4096) return fail(ctx, RT_ERR_INVALID, "render: max_depth out of range [0, 4096]");
     if ((uint64_t)p->nx * p->ny > 0xFFFFFFFFull) return fail(ctx, RT_ERR_INVALID, "render: image too large");
     if (p->shard_count > 1 && p->shard_id >= p->shard_count) return fail(ctx, RT_ERR_INVALID, "render: shard_id >= shard_count");
+    // slot -> (sample, row, column) goes through udiv_inv (rt_kernels.h), exact for quotients below 2^21: the sample index is
+    // capped by the slice size, the row index by this
+    if (rt_shard_rows(p->ny, p->shard_band ? p->shard_band : 1u, p->shard_count, p->shard_id) >= (1u << 21))
+        return fail(ctx, RT_ERR_UNSUPPORTED, "render: a shard of 2^21 or more image rows is not supported");
     return RT_OK;
 }
 
@@ -901,6 +911,9 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             RT_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
             RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         }
+        // (Starting the second chain k depths behind the first — one wait on the first chain's depth-k shading, then free —
+        // so that the chains are in different phases: config 2 62.9 ms -> 69.6 / 71.4 / 71.0 / 72.9 ms for k = 0 / 1 / 2 / 4,
+        // profiles/round3/stagger_sphere_scene.txt.  The chains do best side by side.)
         for (int depth = 0; depth < n_depths; ++depth)
         for (uint32_t grp = 0; grp < n_groups; ++grp) {
             hipStream_t sg = grp ? ctx->stream2 : st;

@@ -114,10 +114,16 @@ __device__ __forceinline__ void path_key(uint64_t seed, uint32_t pix, uint32_t s
     k0 = fmix32(a + samp * 0x9E3779B9u + s_hi);
     k1 = fmix32((a ^ 0xA511E9B3u) + samp * 0xC2B2AE3Du);
 }
+// RT_WHATIF (throw-away builds that price one thing at a time; WRONG images, never in the product library):
+//   1: every draw costs ONE fmix32 instead of two      2: the Perlin turbulence returns a constant
+//   4: random_in_unit_sphere accepts its first try     8: path_key_of_slot is free (key = slot)
+#ifndef RT_WHATIF
+#define RT_WHATIF 0
+#endif
 struct Rng {
     uint32_t k0, k1, ctr;
     __device__ __forceinline__ float next() {
-        uint32_t r = fmix32(fmix32(k0 ^ (ctr * 0x9E3779B9u)) + k1);
+        uint32_t r = (RT_WHATIF & 1) ? fmix32((k0 ^ (ctr * 0x9E3779B9u)) + k1) : fmix32(fmix32(k0 ^ (ctr * 0x9E3779B9u)) + k1);
         ++ctr;
         return (float)(r >> 8) * (1.0f / 16777216.0f);
     }
@@ -137,7 +143,7 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Rng& rng) { // math.rs:17-37
         float y = rng.next();
         float z = rng.next();
         V3 v = v3(x, y, z) * (1.0f - -1.0f) + -1.0f;
-        if (length_squared(v) < 1.0f) return v;
+        if ((RT_WHATIF & 4) || length_squared(v) < 1.0f) return v;
     }
 }
 __device__ __forceinline__ V3 random_on_hemisphere(Rng& rng, V3 n) { // math.rs:43-53
@@ -306,6 +312,7 @@ __device__ inline float perlin_noise(const PerlinTables& pt, uint32_t set, V3 p)
     return accum;
 }
 __device__ inline float perlin_turb(const PerlinTables& pt, uint32_t set, V3 p) { // texture.rs:115-124
+    if (RT_WHATIF & 2) return p.x;
     float accum = 0.0f;
     float w = 1.0f;
     for (int it = 0; it < 7; ++it) {

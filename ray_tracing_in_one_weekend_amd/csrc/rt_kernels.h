@@ -85,6 +85,10 @@ __device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t
 // RNG key of the path in slot `slot` of the slice: the inverse of slot = s_local * npix + pixel_local, then path_key
 // exactly as gen_primary computes it.
 __device__ __forceinline__ void path_key_of_slot(const GenParams& gp, uint32_t slot, uint32_t& k0, uint32_t& k1) {
+    if (RT_WHATIF & 8) {
+        k0 = slot, k1 = slot ^ 0x9E3779B9u;
+        return;
+    }
     uint32_t pl, i;
     const uint32_t s_local = udiv_inv(slot, gp.npix, gp.inv_npix, pl);
     const uint32_t lj = udiv_inv(pl, gp.nx, gp.inv_nx, i);

@@ -2,8 +2,9 @@
 FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (TCC has 4 slots; they do not fit
 one pass) with --kernel-trace only; units are KiB... rocprofv3 reports KB (x1024 here); on gfx950
 FETCH_SIZE reads exactly 1/2 of a wide coalesced (16 B/lane) streaming read, so it is doubled;
-WRITE_SIZE is exact for 16 B/lane streaming stores.  (Our loads: 16 B/lane queue arrays and
-sphere records, 8 B hit records; the x2 is exact for the former and an upper bound for the rest.)
+WRITE_SIZE is exact for 16 B/lane streaming stores.  The x2 was calibrated in round 3 for the access patterns of the trace
+kernels (coalesced 4-32 B, gathers of 4-32 B out of scattered lines): it is exact for all of them — the L2 fetches whole
+128 B lines with one request each (profiles/round3/fetch_calibration.json).
 
 Run on the GPU box:  python scripts/collect_traffic.py profiles/round1/traffic.json [bench args]
 Writes the JSON that bench.py reports as roofline.traffic (per launch, like roofline.achieved).
@@ -44,8 +45,14 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             if counter == "FETCH_SIZE" and row["Dispatch_Id"] not in seen:
                 seen.add(row["Dispatch_Id"])
                 launches[k] += 1
+# FETCH_SIZE x2: calibrated on this chip for streams AND gathers (scripts/micro/fetch_gather.hip,
+# profiles/round3/fetch_calibration.json): every L2 miss is ONE request for the whole 128 B line, tallied at 64 B, whether the
+# wave wanted 4, 16 or 2 x 16 B of it.  WRITE_SIZE: exact for coalesced stores; a scattered 8-32 B store to one line counts 32 B.
 res = {"command": "bench.py " + " ".join(bench_args), "kernels": {}, "fetch_correction": 2.0,
-       "note": "FETCH_SIZE x2 (gfx950 wide-load undercount), WRITE_SIZE x1; KB x 1024; separate --pmc passes"}
+       "fetch_correction_source": "profiles/round3/fetch_calibration.json (lines * 128 B / FETCH_SIZE = 2.000 for all ten read patterns)",
+       "library_build_id": (bench_line or {}).get("library_build_id"),
+       "note": "FETCH_SIZE x2 = 128 B lines fetched by the L2 (gfx950 tallies the 128 B request at 64 B), WRITE_SIZE x1; KB x 1024; "
+               "separate --pmc passes"}
 total_bytes = 0.0
 for k in KERNELS:
     fb = tot[(k, "FETCH_SIZE")] * 1024.0 * 2.0

@@ -68,6 +68,7 @@ for k in KERNELS:
     }
 if bench_line:
     res["bench_config"] = bench_line.get("config")
+    res["library_build_id"] = bench_line.get("library_build_id")
 os.makedirs(os.path.dirname(os.path.abspath(out_json)), exist_ok=True)
 json.dump(res, open(out_json, "w"), indent=1)
 print(json.dumps(res))

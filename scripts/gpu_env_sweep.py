@@ -1,7 +1,8 @@
 """Interleaved sweep of an environment knob in one process:
 python scripts/gpu_env_sweep.py <scene> <spp> <rounds> <ENV_NAME> v0 v1 ...   -> median device ms per value
 Every value gets its own context (knobs read by rt_scene_upload) and the variable is also set around each render
-(knobs read by rt_render); the value "-" means unset."""
+(knobs read by rt_render); the value "-" means unset.  RTOW_SWEEP_FLAGS=0 renders the production frame (two chains on two
+streams, no per-depth timing) instead of the single chain that per-depth timing needs."""
 import os
 import statistics
 import sys
@@ -22,13 +23,15 @@ def setenv(v):
         os.environ[env] = v
 
 
+one_ctx = os.environ.get("RTOW_SWEEP_ONE_CTX") == "1"  # a knob read per render: one context for all values (its buffers, its slice size)
 for v in values:
     setenv(v)
-    r = rt.Renderer(0)
-    r.upload(scene)
+    r = rends[0] if (one_ctx and rends) else rt.Renderer(0)
+    if not (one_ctx and rends):
+        r.upload(scene)
     rends.append(r)
 os.environ.pop(env, None)
-p = rt.make_params(1080 if square else 1920, 1080, spp, max_depth=50, flags=rt._ffi.FLAG_TIME_DEPTHS)
+p = rt.make_params(1080 if square else 1920, 1080, spp, max_depth=50, flags=int(os.environ.get("RTOW_SWEEP_FLAGS", rt._ffi.FLAG_TIME_DEPTHS)))  # 0: the production two-chain frame
 res = {v: [] for v in values}
 ref = None
 for it in range(rounds + 1):

@@ -17,7 +17,8 @@ def built():
     """Native libraries: prebuilt in-tree (they travel with the snapshot); build if missing."""
     from ray_tracing_in_one_weekend_amd import build as b
     b.build_host_library()
-    b.build_oracle()
+    from oracle import build as ob
+    ob.build_oracle()
     if not os.path.exists(os.path.join(b.PKG_DIR, "librtow_mi355x.so")):
         b.build_gpu_library()
     return True

@@ -23,7 +23,8 @@ def test_gpu_library_exports_every_declared_symbol(rt):
     assert set(names) == set(rt._ffi.GPU_SYMBOLS), (names, rt._ffi.GPU_SYMBOLS)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.rt_abi_version() == 6 == rt._ffi.EXPECTED_ABI
+    assert lib.rt_abi_version() == 7 == rt._ffi.EXPECTED_ABI
+    assert len(lib.rt_build_id()) in (7, 16)  # "unknown" or 16 hex digits
 
 
 def test_host_library_exports_every_declared_symbol(rt):
