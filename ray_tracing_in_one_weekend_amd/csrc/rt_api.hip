@@ -745,8 +745,15 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     const bool bvh_ok = ds.n_prims > 0 && ds.n_bvh4_nodes > 0 && ds.n_bvh4_nodes < 32768 && n_entries <= 32768 &&
                         bvh.depth <= RT_BVH_MAX_DEPTH;
     const char* force_hbm = getenv("RTOW_BVH_HBM");   // test hook: traverse out of HBM even when LDS would fit
-    ctx->bvh_in_lds = bvh_ok && bvh_lds_bytes(ds, RT_BVH_BLOCK, true) <= ctx->lds_limit &&
-                      !(force_hbm && force_hbm[0] == '1');
+    // General scenes (wrappers, rectangles, media): the tree goes to LDS only when TWO workgroups per CU still fit.  Their
+    // traversal is bound by dependent loads, and 8 waves per SIMD reading the tree through L2 beat 4 waves reading it from
+    // LDS: a final_scene-like scene of 600-1 300 primitives runs 16-19 % faster with its tree in L2 and two workgroups than
+    // with tree AND wrapper tables in LDS and one (profiles/round3/final_like.txt) — which is also why final_scene's tree was
+    // not squeezed into LDS with quantised boxes: 1 150 nodes x 48 B + 56 KB of stacks leave room for one workgroup only.
+    // Sphere-only scenes keep their faster LDS-only kernel (sorted slab planes) even at one workgroup per CU.
+    const bool general = ds.n_rects > 0 || ds.n_xforms > 0 || ds.n_media > 0;
+    const size_t lds_budget = general ? ctx->lds_limit / 2 : ctx->lds_limit;
+    ctx->bvh_in_lds = bvh_ok && bvh_lds_bytes(ds, RT_BVH_BLOCK, true) <= lds_budget && !(force_hbm && force_hbm[0] == '1');
     ctx->isect_lds = bvh_lds_bytes(ds, RT_BVH_BLOCK, ctx->bvh_in_lds);
     ctx->use_bvh = bvh_ok && ctx->isect_lds <= ctx->lds_limit;
     // general scenes: wrapper / medium tables behind the tree carve, when two workgroups per CU still fit
@@ -894,7 +901,13 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     // half-size grids in lockstep).  The two half-grid launches of a depth run side by side, so a "launch" in RtStats is
     // the logical one — one kernel, one depth, all shards — and rocprof shows each half lasting about that long.
     // Per-depth timing needs the single chain.
-    const uint32_t n_groups = (nq >= 2u * RT_ISECT_MAX_SHARDS && !time_depths && !getenv("RTOW_ONE_STREAM")) ? 2u : 1u;
+    // Scenes whose k_intersect waits on dependent loads like k_shade does — wrapper chains, media, a tree read through L2 —
+    // run ONE chain: two would only share the same pipes (final_scene 41.4 -> 39.3 ms, cornell_box 32.7 -> 30.8 ms per 64 spp
+    // with one; sphere_scene 18.0 -> 18.6, simple_light_scene's bare rectangles likewise prefer two:
+    // profiles/round3/one_stream.txt).  RTOW_ONE_STREAM=1 / =0 force either (experiment knob).
+    const char* one_env = getenv("RTOW_ONE_STREAM");
+    const bool one_chain = one_env ? one_env[0] == '1' : (ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0 || (use_bvh && !ctx->bvh_in_lds));
+    const uint32_t n_groups = (nq >= 2u * RT_ISECT_MAX_SHARDS && !time_depths && !one_chain) ? 2u : 1u;
     const uint32_t shards_per_wg = (nq + isect_grid - 1u) / isect_grid;
     // selects the "general scene" kernel instantiations (rectangles and Translate / RotateY wrappers)
     const bool rects = scene_is_general(ctx);
