@@ -226,7 +226,15 @@ QueueGeom queue_geom(const RtCtx* ctx, uint32_t n_max) {
     // k_intersect: as many 1024-thread workgroups per CU as LDS admits (two at <= 64 VGPRs); every
     // workgroup owns nq / isect_grid shards
     const uint32_t isect_wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, ctx->lds_limit / std::max<size_t>(ctx->isect_lds, 1)));
-    g.isect_grid = std::min(g.nq, (uint32_t)ctx->n_cu * isect_wg_per_cu);
+    // ... in TWO rounds when the tree is more than a handful of nodes: a workgroup's persistent lanes end in a drain phase (its
+    // work counter is empty, the last rays finish in ever emptier waves), and with exactly one resident round all workgroups
+    // drain together; with twice as many, half as long, the drain of the first round runs under the bulk of the second.
+    // config 2: 61.9 -> 59.8 ms (-3.4 %), pbr_sweep_scene -3.6 %; scenes of a few primitives (simple_light_scene +5.6 %) and
+    // trees read through L2 (final_scene +1.9 %) do better with one round (profiles/round3/nq_sweep*.txt; non-multiples of
+    // the resident count lose outright: 1 280 / 1 792 workgroups 60.6 / 62.0 ms).
+    const uint32_t rounds = (ctx->bvh_in_lds && ctx->ds.n_bvh4_nodes >= 64u) ? 2u : 1u;
+    g.isect_grid = std::min(g.nq, (uint32_t)ctx->n_cu * isect_wg_per_cu * rounds);
+    if (const char* e = getenv("RTOW_ISECT_GRID")) g.isect_grid = std::min(g.nq, (uint32_t)std::max(1, atoi(e))); // experiment knob
     while ((g.nq + g.isect_grid - 1) / g.isect_grid > RT_ISECT_MAX_SHARDS) g.isect_grid *= 2;
     g.isect_grid = std::min(g.isect_grid, g.nq);
     const uint32_t nchunks = (n_max + 255u) / 256u;

@@ -16,7 +16,21 @@ rt.register_default_images()
 square = scene_name in ("cornell_box", "final_scene")
 scene = rt.Scene.build(scene_name, 1.0 if square else 16 / 9)
 rends = []
+_last = []
+
+
 def setenv(v):
+    """`env` = "+": every value is a list NAME=VALUE[,NAME=VALUE...] (several knobs at once; "-" = none set)"""
+    if env == "+":
+        for k in _last:
+            os.environ.pop(k, None)
+        _last.clear()
+        if v != "-":
+            for kv in v.split(","):
+                k, val = kv.split("=", 1)
+                os.environ[k] = val
+                _last.append(k)
+        return
     if v == "-":
         os.environ.pop(env, None)
     else:
@@ -38,7 +52,7 @@ for it in range(rounds + 1):
     for v, r in zip(values, rends):
         setenv(v)
         img, _, st = r.render(scene.camera, p)
-        os.environ.pop(env, None)
+        setenv("-")
         a, b, n = r.depth_timings()
         if ref is None:
             ref = img.copy()
@@ -47,4 +61,4 @@ for it in range(rounds + 1):
             res[v].append((st.seconds_device * 1e3, st.n_rays, a.sum(), b.sum()))
 for v in values:
     t = statistics.median(x[0] for x in res[v])
-    print(f"{scene_name:14s} {env}={v:>6s}: {t:8.2f} ms  {res[v][0][1] / t / 1e3:8.0f} Mray/s  isect {statistics.median(x[2] for x in res[v]):7.2f} shade {statistics.median(x[3] for x in res[v]):7.2f}", flush=True)
+    print(f"{scene_name:14s} {env}={v:>34s}: {t:8.2f} ms  {res[v][0][1] / t / 1e3:8.0f} Mray/s  isect {statistics.median(x[2] for x in res[v]):7.2f} shade {statistics.median(x[3] for x in res[v]):7.2f}", flush=True)
