@@ -244,8 +244,16 @@ void shuffle(Xoshiro256pp& rng, std::vector<T>& v) {
 
 /* ------------------------------------------------------------------------------------------
  * Counter-based generator shared (by specification, not by code) with the GPU kernels.
- * DESIGN.md "RNG": draw(k0,k1,ctr) = fmix32(fmix32(k0 ^ ctr*0x9E3779B9) + k1).
+ * DESIGN.md "RNG": draw(k0,k1,ctr) = mix32((k0 ^ ctr*0x9E3779B9) + k1), mix32 = the lowbias32 finaliser.
  * ---------------------------------------------------------------------------------------- */
+inline uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
 inline uint32_t fmix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
@@ -261,7 +269,7 @@ inline void ctr_path_key(uint64_t seed, uint32_t pix, uint32_t samp, uint32_t& k
     k1 = fmix32((a ^ 0xA511E9B3u) + samp * 0xC2B2AE3Du);
 }
 inline uint32_t ctr_draw(uint32_t k0, uint32_t k1, uint32_t ctr) {
-    return fmix32(fmix32(k0 ^ (ctr * 0x9E3779B9u)) + k1);
+    return mix32((k0 ^ (ctr * 0x9E3779B9u)) + k1);
 }
 
 /* lib.rs:7-9 thread-local RNG, abstracted over the two modes. */

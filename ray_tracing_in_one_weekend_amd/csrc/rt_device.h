@@ -97,14 +97,29 @@ __device__ unsigned long long g_lane_stats[RT_LANE_STAT_N];
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based RNG (DESIGN.md "RNG"); replaces the thread-local SmallRng of lib.rs:7-9.
-// draw(k0,k1,ctr) = fmix32(fmix32(k0 ^ ctr*0x9E3779B9) + k1); f32 = (u32 >> 8) * 2^-24 exactly
+// draw(k0,k1,ctr) = mix32((k0 ^ ctr*0x9E3779B9) + k1); f32 = (u32 >> 8) * 2^-24 exactly
 // as rand's Standard distribution maps a u32 (main.rs:89-90, math.rs:19-21).
+// A SplitMix-style generator per path: a keyed Weyl sequence (ctr * golden ratio, scrambled by the path's two 32-bit keys,
+// themselves three fmix32 rounds over seed / pixel / sample) through ONE 32-bit finaliser with full avalanche.  Rounds 1-2
+// used two (fmix32(fmix32(..) + k1)): the second costs 7.5 % of k_shade (profiles/round3/whatif_shade_costs.txt: the draws
+// are quarter-rate integer multiplies) and buys nothing measurable — uniformity, 3-D equidistribution of the ball sampler's
+// triples, serial and neighbour-pixel correlation and counter-bit avalanche are the same (tests/test_oracle_kat.py).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
     h ^= h >> 13;
     h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+// the per-draw finaliser: "lowbias32" (C. Wellons, hash-prospector, public domain): the two-multiply xorshift-multiply
+// construction of fmix32 with the constants of lowest measured avalanche bias
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
     h ^= h >> 16;
     return h;
 }
@@ -115,7 +130,7 @@ __device__ __forceinline__ void path_key(uint64_t seed, uint32_t pix, uint32_t s
     k1 = fmix32((a ^ 0xA511E9B3u) + samp * 0xC2B2AE3Du);
 }
 // RT_WHATIF (throw-away builds that price one thing at a time; WRONG images, never in the product library):
-//   1: every draw costs ONE fmix32 instead of two      2: the Perlin turbulence returns a constant
+//   1: every draw costs TWO mixing rounds (rounds 1-2)  2: the Perlin turbulence returns a constant
 //   4: random_in_unit_sphere accepts its first try     8: path_key_of_slot is free (key = slot)
 #ifndef RT_WHATIF
 #define RT_WHATIF 0
@@ -123,7 +138,7 @@ __device__ __forceinline__ void path_key(uint64_t seed, uint32_t pix, uint32_t s
 struct Rng {
     uint32_t k0, k1, ctr;
     __device__ __forceinline__ float next() {
-        uint32_t r = (RT_WHATIF & 1) ? fmix32((k0 ^ (ctr * 0x9E3779B9u)) + k1) : fmix32(fmix32(k0 ^ (ctr * 0x9E3779B9u)) + k1);
+        uint32_t r = (RT_WHATIF & 1) ? fmix32(fmix32(k0 ^ (ctr * 0x9E3779B9u)) + k1) : mix32((k0 ^ (ctr * 0x9E3779B9u)) + k1);
         ++ctr;
         return (float)(r >> 8) * (1.0f / 16777216.0f);
     }

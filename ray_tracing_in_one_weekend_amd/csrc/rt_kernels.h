@@ -390,7 +390,7 @@ __device__ __forceinline__ bool medium_root(const Tables& sc, const float4* geo,
     if (t1 >= t2) return false;
     if (t1 < 0.0f) t1 = 0.0f;
     const float dist_inside_boundary = (t2 - t1) * ray_len;
-    const uint32_t r = fmix32(fmix32(mc.k0 ^ ((mc.base + 224u + m) * 0x9E3779B9u)) + mc.k1);
+    const uint32_t r = mix32((mc.k0 ^ ((mc.base + 224u + m) * 0x9E3779B9u)) + mc.k1);
     const float xi = (float)(r >> 8) * (1.0f / 16777216.0f);
     const float hit_dist = sc.med_neg_inv_density[m] * logf(xi);
     if (hit_dist > dist_inside_boundary) return false;

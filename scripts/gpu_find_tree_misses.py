@@ -39,8 +39,18 @@ def fmix32(h):
     return h
 
 
+def mix32(h):
+    h = h & M32
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7FEB352D)) & M32
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x846CA68B)) & M32
+    h ^= h >> np.uint64(16)
+    return h
+
+
 def draw(k0, k1, ctr):
-    return fmix32((fmix32(k0 ^ ((np.uint64(ctr) * np.uint64(0x9E3779B9)) & M32)) + k1) & M32)
+    return mix32(((k0 ^ ((np.uint64(ctr) * np.uint64(0x9E3779B9)) & M32)) + k1) & M32)
 
 
 cam = scene.camera

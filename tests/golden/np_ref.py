@@ -42,7 +42,7 @@ def lerp(a, b, s): return a + (b - a) * s  # math.rs:154-156
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# counter RNG: draw(k0, k1, ctr) = fmix32(fmix32(k0 ^ ctr * 0x9E3779B9) + k1); f32 = (u32 >> 8) * 2^-24
+# counter RNG: draw(k0, k1, ctr) = mix32((k0 ^ ctr * 0x9E3779B9) + k1); f32 = (u32 >> 8) * 2^-24
 # ---------------------------------------------------------------------------------------------------------------
 def fmix32(h):
     h &= U32
@@ -50,6 +50,16 @@ def fmix32(h):
     h = (h * 0x85EBCA6B) & U32
     h ^= h >> 13
     h = (h * 0xC2B2AE35) & U32
+    h ^= h >> 16
+    return h
+
+
+def mix32(h):  # the per-draw finaliser (lowbias32)
+    h &= U32
+    h ^= h >> 16
+    h = (h * 0x7FEB352D) & U32
+    h ^= h >> 15
+    h = (h * 0x846CA68B) & U32
     h ^= h >> 16
     return h
 
@@ -65,7 +75,7 @@ class Rng:
         self.k0, self.k1, self.ctr = int(k0), int(k1), (depth + 1) * 256
 
     def next(self):  # rand's Standard f32: top 24 bits of a u32 times 2^-24 (main.rs:89-90, math.rs:19-21)
-        r = fmix32((fmix32(self.k0 ^ ((self.ctr * 0x9E3779B9) & U32)) + self.k1) & U32)
+        r = mix32(((self.k0 ^ ((self.ctr * 0x9E3779B9) & U32)) + self.k1) & U32)
         self.ctr += 1
         return f32(r >> 8) * f32(1.0 / 16777216.0)
 

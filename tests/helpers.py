@@ -42,6 +42,23 @@ def fmix32(h):
     return h
 
 
+def mix32(h):
+    """the per-draw finaliser of the counter RNG (lowbias32) on uint32 arrays"""
+    h = np.asarray(h, dtype=np.uint64) & 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x7FEB352D) & 0xFFFFFFFF
+    h ^= h >> 15
+    h = (h * 0x846CA68B) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def ctr_draw(k0, k1, ctr):
+    """draw(k0, k1, ctr) = mix32((k0 ^ ctr * 0x9E3779B9) + k1) on uint32 arrays (DESIGN.md "RNG")"""
+    k0, k1 = np.asarray(k0, dtype=np.uint64), np.asarray(k1, dtype=np.uint64)
+    return mix32(((k0 ^ ((np.asarray(ctr, dtype=np.uint64) * 0x9E3779B9) & 0xFFFFFFFF)) + k1) & 0xFFFFFFFF)
+
+
 def path_keys(seed, pix, samp):
     """(k0, k1) of path (pixel, sample) as uint32 [n, 2] — the key the renderer derives for a slot."""
     pix = np.asarray(pix, dtype=np.uint64)

@@ -11,7 +11,7 @@ whose product chain is associated differently from the wavefront's T *= a.
 import numpy as np
 import pytest
 
-from helpers import display, fmix32, path_keys, rays_on_scene, rmse_display
+from helpers import ctr_draw, display, path_keys, rays_on_scene, rmse_display
 
 pytestmark = pytest.mark.gpu
 
@@ -222,7 +222,7 @@ def test_many_samples_and_uneven_slices(rt, orc, renderer, name, nx, ny):
     p = rt.make_params(nx, ny, 150, max_depth=12)
     img, _, st = renderer.render(scene.camera, p)
     ref, _, so = _oracle(orc, scene, p)
-    assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
+    _rays_agree(st, so, scene, p)
     _compare_frames(orc, scene, p, img, ref, name, rt, renderer)
     for s in (70, 64, 128):
         im2, _, st2 = renderer.render(scene.camera, rt.make_params(nx, ny, 150, max_depth=12, spp_slice=s))
@@ -316,8 +316,7 @@ def _primary_rays(scene, p, pix_i, pix_j, samp):
     k0, k1 = keys[:, 0].astype(np.uint64), keys[:, 1].astype(np.uint64)
 
     def draw(ctr):
-        r = fmix32((fmix32(k0 ^ ((ctr * 0x9E3779B9) & 0xFFFFFFFF)) + k1) & 0xFFFFFFFF)
-        return ((r >> 8).astype(np.float32) * f(1.0 / 16777216.0)).astype(f)
+        return ((ctr_draw(k0, k1, ctr) >> 8).astype(np.float32) * f(1.0 / 16777216.0)).astype(f)
     u = ((pix_i.astype(f) + draw(0)) / f(p.nx)).astype(f)
     v = ((pix_j.astype(f) + draw(1)) / f(p.ny)).astype(f)
     cam = scene.camera
@@ -413,6 +412,57 @@ def _explain_image_outliers(rt, orc, renderer, scene, p, img, it, name, px_tol=1
     return out
 
 
+def _explain_medium_outliers(rt, orc, renderer, scene, p, img, it, name, px_tol=1e-4):
+    """hitable.rs:560-570: a medium's scatter distance is `neg_inv_density * ln(rand)`, and device and host libm differ in
+    the last ulp of ln (the per-bounce tests hold medium hits to 2e-6, everything else bit for bit).  The scatter POINT then
+    differs by an ulp, and every comparison further down that path — a silhouette, a box edge, a dielectric coin flip —
+    sees inputs an ulp apart: now and then one goes the other way and the two paths part for good (cornell_box: about one
+    path in 350 000).  This makes that a tested statement: every pixel that differs from the iterative oracle by more than
+    `px_tol` is re-traced sample by sample through rt_debug_bounce on both sides, and the FIRST bounce at which the two
+    disagree in anything but the last bits must be a medium scatter whose t agrees to 2e-6 (after which the inputs differ and
+    nothing more can be said).  Returns (outlier mask, number of diverged paths)."""
+    fin = np.isfinite(it) & np.isfinite(img)
+    diff = np.abs(display(np.where(fin, img, 0)) - display(np.where(fin, it, 0))).max(axis=2)
+    out = diff > px_tol
+    jj, ii = np.nonzero(out)
+    assert len(jj) <= max(16, int(1e-3 * out.size)), (name, len(jj))
+    n_prims = scene.flat.n_spheres + scene.flat.n_rects
+    diverged = 0
+    for pj, pi in zip(jj, ii):
+        o, d, keys = _primary_rays(scene, p, np.full(p.spp, pi), np.full(p.spp, pj), np.arange(p.spp))
+        live = np.ones(p.spp, dtype=bool)
+        seen = False
+        for depth in range(p.max_depth + 1):
+            idx = np.nonzero(live)[0]
+            if not len(idx):
+                break
+            g = renderer.debug_bounce(o[idx], d[idx], keys[idx], depth=depth)
+            c = orc.debug_bounce(scene.flat_ptr, o[idx], d[idx], keys[idx], depth=depth, accel=orc.ACCEL_LIST)
+            assert np.array_equal(g["hit"], c["hit"]) and np.array_equal(g["alive"], c["alive"]), (name, pi, pj, depth)
+            assert np.array_equal(g["d"].view(np.uint32), c["d"].view(np.uint32)), (name, pi, pj, depth)
+            exact = np.array([np.array_equal(g["t"][k:k + 1].view(np.uint32), c["t"][k:k + 1].view(np.uint32)) and
+                              np.array_equal(g["o"][k].view(np.uint32), c["o"][k].view(np.uint32)) for k in range(len(idx))])
+            for k in np.nonzero(~exact)[0]:  # an ulp apart: only a medium scatter may be, and the path is followed no further
+                assert g["hit"][k] >= n_prims and np.isclose(g["t"][k], c["t"][k], rtol=2e-6), (name, pi, pj, depth, g["hit"][k], g["t"][k], c["t"][k])
+                seen = True
+                diverged += 1
+            alive = g["alive"].astype(bool) & exact
+            o[idx[alive]], d[idx[alive]] = g["o"][alive], g["d"][alive]
+            live[idx[~alive]] = False
+        assert seen, (name, "pixel", int(pi), int(pj), "differs although none of its paths scatters in a medium an ulp apart")
+    print(f"{name}: {len(jj)} of {out.size} pixels differ by more than {px_tol}; each holds a path whose medium scatter point is an ulp apart ({diverged} such paths)")
+    return out, diverged
+
+
+def _rays_agree(st, so, scene, p):
+    """Ray counts per depth: exact — except in a scene with media, where a path whose scatter point is an ulp apart may part from
+    the oracle's (_explain_medium_outliers): there to 1e-4 of the rays, as test_constant_medium_and_cornell_box states it."""
+    if not scene.flat.n_media:
+        assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
+    else:
+        assert abs(int(st.n_rays) - int(so.n_rays)) <= max(16, 1e-4 * so.n_rays), (st.n_rays, so.n_rays)
+
+
 def _compare_frames(orc, scene, p, img, ref, name, rt=None, renderer=None):
     """Frame against the oracle when pixels may be non-finite (pbr.rs: a grazing n_dot_i -> 0 divides by ~0, the
     attenuation overflows and inf * 0 = NaN poisons the pixel in the reference's arithmetic too).
@@ -425,7 +475,11 @@ def _compare_frames(orc, scene, p, img, ref, name, rt=None, renderer=None):
     it, _, _ = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_COUNTER, estimator=orc.EST_ITERATIVE))
     assert np.array_equal(np.isfinite(img), np.isfinite(it)), name
     fin = np.isfinite(it)
-    if scene.flat.n_images:
+    if scene.flat.n_media:
+        assert renderer is not None, "scenes with media need the renderer to re-trace their outliers"
+        fin = fin & ~_explain_medium_outliers(rt, orc, renderer, scene, p, img, it, name)[0][:, :, None]
+        ref = np.where(fin, ref, img)  # (the same pixels are set aside against the recursive order below)
+    elif scene.flat.n_images:
         assert renderer is not None, "scenes with image textures need the renderer to re-trace their outliers"
         fin = fin & ~_explain_image_outliers(rt, orc, renderer, scene, p, img, it, name)[:, :, None]
     e_it = rmse_display(np.where(fin, img, 0), np.where(fin, it, 0))
@@ -708,7 +762,11 @@ def test_russian_roulette_opt_in(rt, orc, renderer):
     ref, _, so = _oracle(orc, scene, p)
     it, _, si = _oracle(orc, scene, p, estimator=orc.EST_ITERATIVE)
     assert st.n_rays == so.n_rays == si.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
-    assert rmse_display(img, it) <= 2e-5 and rmse_display(img, ref) <= RMSE_TOL
+    # (sphere_scene holds an image-textured sphere: pixels with a lookup on a texel edge are shown to be just that and set
+    # aside, _explain_image_outliers; the re-trace follows the path's own draws, which roulette leaves untouched — it takes
+    # the counter after them, DESIGN.md "RNG")
+    keep = ~_explain_image_outliers(rt, orc, renderer, scene, p, img, it, "sphere_scene + russian roulette")[:, :, None]
+    assert rmse_display(np.where(keep, img, 0), np.where(keep, it, 0)) <= 2e-5 and rmse_display(img, ref) <= RMSE_TOL
     plain, _, sp = renderer.render(scene.camera, rt.make_params(320, 180, 16, max_depth=50))
     assert st.n_rays < 0.9 * sp.n_rays
     # unbiased: compare LINEAR means (the gamma/clamp of the display transform is not linear in the noise)

@@ -156,6 +156,38 @@ def test_counter_rng_is_a_function_of_key_and_counter(orc):
     assert abs(u.mean() - 0.5) < 0.02 and abs(u.var() - 1 / 12) < 0.01
 
 
+def test_counter_draw_statistics(orc):
+    """The per-draw hash of the counter RNG (DESIGN.md "RNG": one lowbias32 round over a keyed Weyl sequence) on the key
+    set a frame actually uses — 2^20 consecutive pixels, the counters of one depth block: uniform in 1-D (4096 bins) and in
+    the 3-D cells the ball sampler's (x, y, z) triples fall into (math.rs:28-37), no serial correlation between a path's
+    consecutive draws nor between neighbouring pixels, acceptance rate of the rejection loop = pi/6, and every counter bit
+    flips every one of the 24 output bits used (main.rs:89-90 keeps the top 24) with probability 1/2."""
+    from helpers import ctr_draw, path_keys
+    from scipy import stats
+    lib = orc.load()
+    n = 1 << 20
+    keys = path_keys(95, np.arange(n), np.zeros(n, dtype=np.uint64)).astype(np.uint64)
+    k0, k1 = keys[:, 0], keys[:, 1]
+    for c in (0, 1, 256, 12345):  # the numpy restatement used below is the oracle's function
+        assert int(ctr_draw(k0[7], k1[7], c)) == lib.orc_ctr_draw(int(k0[7]), int(k1[7]), c)
+    u = [(ctr_draw(k0, k1, 256 + i) >> 8).astype(np.float64) / 16777216.0 for i in range(4)]
+    cnt = np.bincount((u[0] * 4096).astype(np.int64), minlength=4096)
+    assert stats.chi2.sf(((cnt - n / 4096) ** 2 / (n / 4096)).sum(), 4095) > 1e-4
+    cells = (np.floor(u[0] * 16) * 256 + np.floor(u[1] * 16) * 16 + np.floor(u[2] * 16)).astype(np.int64)
+    cnt = np.bincount(cells, minlength=4096)
+    assert stats.chi2.sf(((cnt - n / 4096) ** 2 / (n / 4096)).sum(), 4095) > 1e-4
+    assert abs(np.corrcoef(u[0], u[1])[0, 1]) < 5e-3 and abs(np.corrcoef(u[0][:-1], u[0][1:])[0, 1]) < 5e-3
+    v = [2.0 * x - 1.0 for x in u[:3]]
+    assert abs(((v[0] ** 2 + v[1] ** 2 + v[2] ** 2) < 1.0).mean() - np.pi / 6) < 2e-3
+    rng = np.random.default_rng(3)
+    a0, a1 = rng.integers(0, 2 ** 32, 1 << 16, dtype=np.uint64), rng.integers(0, 2 ** 32, 1 << 16, dtype=np.uint64)
+    ctr = rng.integers(0, 1 << 14, 1 << 16, dtype=np.uint64)
+    for bit in range(14):
+        x = (ctr_draw(a0, a1, ctr) ^ ctr_draw(a0, a1, ctr ^ np.uint64(1 << bit))) >> 8
+        flips = np.array([((x >> k) & 1).mean() for k in range(24)])
+        assert np.abs(flips - 0.5).max() < 0.012, (bit, flips)  # 6 sigma at 2^16 samples
+
+
 def test_rect_hit_known_answers(orc):
     """hitable.rs:244-362: t = (k - o)/d on the constant axis, bounds inclusive, uv = (p - min)/(max - min)."""
     lib = orc.load()
