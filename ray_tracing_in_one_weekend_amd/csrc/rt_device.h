@@ -135,11 +135,15 @@ __device__ __forceinline__ void path_key(uint64_t seed, uint32_t pix, uint32_t s
 #ifndef RT_WHATIF
 #define RT_WHATIF 0
 #endif
+// `w` is the Weyl term ctr * 0x9E3779B9 of the NEXT draw, advanced by an addition: the same values as the product, and one
+// quarter-rate integer multiply less per draw (two are left, in mix32).
 struct Rng {
-    uint32_t k0, k1, ctr;
+    uint32_t k0, k1, w;
+    __device__ __forceinline__ Rng() {}
+    __device__ __forceinline__ Rng(uint32_t k0_, uint32_t k1_, uint32_t ctr) : k0(k0_), k1(k1_), w(ctr * 0x9E3779B9u) {}
     __device__ __forceinline__ float next() {
-        uint32_t r = (RT_WHATIF & 1) ? fmix32(fmix32(k0 ^ (ctr * 0x9E3779B9u)) + k1) : mix32((k0 ^ (ctr * 0x9E3779B9u)) + k1);
-        ++ctr;
+        uint32_t r = (RT_WHATIF & 1) ? fmix32(fmix32(k0 ^ w) + k1) : mix32((k0 ^ w) + k1);
+        w += 0x9E3779B9u;
         return (float)(r >> 8) * (1.0f / 16777216.0f);
     }
 };

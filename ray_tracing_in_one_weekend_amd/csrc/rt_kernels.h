@@ -112,7 +112,7 @@ __device__ __forceinline__ void gen_primary(const GenParams& gp, uint32_t idx, V
     const uint32_t samp = gp.s0 + s_local;
     Rng rng;
     path_key(((uint64_t)gp.seed_hi << 32) | gp.seed_lo, j * gp.nx + i, samp, rng.k0, rng.k1);
-    rng.ctr = 0;
+    rng.w = 0u; // counter 0
     // main.rs:89-90
     const float u = ((float)i + rng.next()) / (float)gp.nx;
     const float v = ((float)j + rng.next()) / (float)gp.ny;
