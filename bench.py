@@ -210,6 +210,9 @@ def main():
     ap.add_argument("--spp-slice", type=int, default=0)
     ap.add_argument("--band", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only the warm-up and the timed steps: no CPU baseline, no host-inclusive leg, no in-library check (the runs "
+                         "that rocprofv3 counts: scripts/collect_traffic.py, collect_valu.py, the kernel statistics)")
     ap.add_argument("--in-library", action="store_true",
                     help="after the timed region, rank 0 also renders through rt_multi_render (one process, all --gpus devices, the RCCL "
                          "gather inside the library) and reports bit-identity with rt_render; always on when --gpus > 1")
@@ -352,7 +355,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     in_library = None
-    if rank == 0 and (args.in_library or world > 1):
+    if rank == 0 and (args.in_library or world > 1) and not args.timed_only:
         in_library = in_library_check(rt, scene, renderer, (nx, ny, spp_total, args.max_depth), world)
     if rank == 0:
         s0 = stats[-1]
@@ -407,7 +410,7 @@ def main():
                            "device_seconds_per_step": round(s0.seconds_device, 6),
                            "hbm_frac": round(s0.bytes_algorithmic / max(s0.seconds_device, 1e-12) / 1e9 / HBM_PEAK_GBPS, 5)},
         }
-        if world == 1:
+        if world == 1 and not args.timed_only:
             # the same frame handed to the HOST as the reference's output is (f32 frame + flipped RGB8 through rt_render:
             # the D2H copies included), never `value`: reported beside it
             th0 = time.perf_counter()
@@ -418,7 +421,7 @@ def main():
             out["value_host_inclusive"] = round(host_rays / (time.perf_counter() - th0) / 1e6, 3)
         if args.in_library or world > 1:
             out["in_library"] = in_library
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.timed_only:
             out["cpu_baseline"] = cpu_baseline(rt, scene, cfg["scene"], nx, ny, args.max_depth)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 2)
         print(json.dumps(out), flush=True)

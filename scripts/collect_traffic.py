@@ -19,7 +19,7 @@ import sys
 import tempfile
 
 out_json = sys.argv[1]
-bench_args = sys.argv[2:] or ["--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+bench_args = sys.argv[2:] or ["--steps", "1", "--warmup", "0", "--timed-only"]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("TMPDIR", "/tmp")
 KERNELS = ("k_intersect", "k_shade")

@@ -23,15 +23,15 @@ prof=$(ls -d profiles/round* | sort -V | tail -1)
 cp $out/valu_peak.json $prof/valu_peak.json
 step 400 $py scripts/collect_traffic.py $out/traffic_config2.json > $out/traffic_config2.log 2>&1
 step 400 $py scripts/collect_valu.py $out/valu_config2.json > $out/valu_config2.log 2>&1
-step 400 $py scripts/collect_traffic.py $out/traffic_config4.json --config 4 --steps 1 --warmup 0 --no-cpu-baseline > $out/traffic_config4.log 2>&1
-step 400 $py scripts/collect_traffic.py $out/traffic_config5.json --config 5 --steps 1 --warmup 0 --no-cpu-baseline > $out/traffic_config5.log 2>&1
+step 400 $py scripts/collect_traffic.py $out/traffic_config4.json --config 4 --steps 1 --warmup 0 --timed-only > $out/traffic_config4.log 2>&1
+step 400 $py scripts/collect_traffic.py $out/traffic_config5.json --config 5 --steps 1 --warmup 0 --timed-only > $out/traffic_config5.log 2>&1
 cp $out/traffic_config2.json $out/traffic_config4.json $out/traffic_config5.json $out/valu_config2.json $prof/
 step 300 $py bench.py --steps 20 --warmup 5 > $out/bench_config2.json 2> $out/bench_config2.err
 for c in 3 4 5; do step 300 $py bench.py --config $c --steps 3 --warmup 1 > $out/bench_config$c.json 2> $out/bench_config$c.err; done
 for c in 2 4 5; do
   extra=""; [ $c != 2 ] && extra="--config $c"
   rm -rf $out/prof_tmp
-  step 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_tmp -- $py bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline > $out/kernel_stats_config$c.log 2>&1
+  step 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_tmp -- $py bench.py $extra --steps 2 --warmup 1 --timed-only > $out/kernel_stats_config$c.log 2>&1
   find $out/prof_tmp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats_config$c.csv
 done
 rm -rf $out/prof_tmp
