@@ -162,17 +162,9 @@ def in_library_check(rt, scene, renderer, frame, n_dev, timeout_s=150.0):
         except Exception as e:  # noqa: BLE001 (reported in the JSON line)
             res["error"] = repr(e)[:400]
 
-    # RCCL prints a version banner on stdout when a communicator is created: this process's stdout carries ONE JSON line, so
-    # file descriptor 1 points at stderr while the check runs
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
     th = threading.Thread(target=work, daemon=True)
     th.start()
     th.join(timeout_s)
-    sys.stdout.flush()
-    os.dup2(saved, 1)
-    os.close(saved)
     if th.is_alive():
         res["error"], res["hung"] = f"no result after {timeout_s:.0f} s", True
     return res
@@ -225,6 +217,17 @@ def main():
     if n_req > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(n_req))
 
+    # This process's stdout carries exactly ONE line, the JSON record of rank 0.  Libraries print banners there (RCCL its version
+    # when a communicator comes up, gloo its peer count): file descriptor 1 points at stderr from here on, and the record goes to
+    # the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(record):
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(record) + "\n").encode())
+
     import torch
     import torch.distributed as dist
 
@@ -264,9 +267,9 @@ def main():
             dist.barrier()
         if rank == 0:
             ran = "nccl" if (on_rccl and world > 1) else "gloo"
-            print(json.dumps({"launcher_check": ok, "n_gpus": world, "rccl_ranks": world if ran == "nccl" else 0,
-                              "backend": ran, "gather": "RCCL all_gather over xGMI" if ran == "nccl" else
-                              "gloo all_gather through host memory (rehearsal)"}))
+            emit({"launcher_check": ok, "n_gpus": world, "rccl_ranks": world if ran == "nccl" else 0,
+                  "backend": ran, "gather": "RCCL all_gather over xGMI" if ran == "nccl" else
+                  "gloo all_gather through host memory (rehearsal)"})
         if world > 1:
             dist.destroy_process_group()
         sys.exit(0 if ok else 1)
@@ -424,7 +427,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.timed_only:
             out["cpu_baseline"] = cpu_baseline(rt, scene, cfg["scene"], nx, ny, args.max_depth)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 2)
-        print(json.dumps(out), flush=True)
+        emit(out)
         if in_library and in_library.get("hung"):
             os._exit(0)  # the line is out; do not wait for a wedged collective at interpreter exit
     renderer.close()
