@@ -876,6 +876,16 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     {   // udiv_inv: reciprocals that keep the float quotient at or below the true one
         auto inv = [](uint32_t d) { return (float)((1.0 / (double)d) * (1.0 - 1.0 / 4194304.0)); };
         gp.inv_npix = inv(npix), gp.inv_nx = inv(nx), gp.inv_band = inv(band);
+        // 8 x 8 pixel tiles per wave of depth 0 when the shard's frame allows it (rt_kernels.h GenParams): a strip of 64 x 1 pixels
+        // crosses more silhouettes than a block of 8 x 8, and at depth 0 a wave runs the union of what its lanes hit.  Frames are
+        // bit-identical (keys and the resolve order are functions of (pixel, sample)).  sphere_scene: depth-0 shading 7.17 -> 6.67 ms
+        // per 128 spp, frame 58.6 -> 57.4 ms; pbr_sweep_scene -1.5 %; cornell_box +-0; final_scene +1.7 % (its deeper bounces,
+        // 42.0 -> 43.6 ms of k_intersect), so general scenes keep the rows (profiles/round3/ab_tiles.txt).
+        const char* rm = getenv("RTOW_ROW_MAJOR"); // experiment knob: 1 = rows, 0 = tiles wherever the frame allows
+        const bool want_tiles = rm ? rm[0] == '0' : !scene_is_general(ctx);
+        gp.tiles_per_row = (nx % 8u == 0u && rows >= 8u && want_tiles) ? nx / 8u : 0u;
+        gp.tile_pixels = gp.tiles_per_row * 64u * (rows / 8u); // the last rows % 8 rows stay row-major
+        gp.inv_tpr = gp.tiles_per_row ? inv(gp.tiles_per_row) : 0.0f;
     }
     // Candidate lists of the primary rays, once per frame (k_primary_lists): worth it when the samples of a pixel
     // share them (>= 4 spp) and pixels see few entries.  Measured per 128-spp slice: sphere_scene (533 entries)
@@ -997,14 +1007,14 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         if (ctx->progress_armed && ctx->progress_fn && sl + 1 < n_slices) { // the last slice is the final image itself
             const uint32_t done = s0 + sc;
             hipLaunchKernelGGL(k_finalize, dim3((npix + 255u) / 256u), dim3(256), 0, st, acc, (float*)nullptr,
-                               (uint8_t*)ctx->preview_u8.p, nx, rows, done);
+                               (uint8_t*)ctx->preview_u8.p, nx, rows, done, gp.tiles_per_row, gp.tile_pixels);
             RT_HIP(ctx, hipMemcpyAsync(ctx->preview_host.data(), ctx->preview_u8.p, (size_t)npix * 3, hipMemcpyDeviceToHost, st));
             RT_HIP(ctx, hipStreamSynchronize(st));
             ctx->progress_fn(ctx->progress_user, done, spp, ctx->preview_host.data(), nx, rows);
         }
     }
     hipLaunchKernelGGL(k_finalize, dim3((npix + 255u) / 256u), dim3(256), 0, st, acc, (float*)d_out_rgb_f32,
-                       (uint8_t*)d_out_rgb8, nx, rows, spp);
+                       (uint8_t*)d_out_rgb8, nx, rows, spp, gp.tiles_per_row, gp.tile_pixels);
     RT_HIP(ctx, hipEventRecord(ctx->ev_end, st));
     RT_HIP(ctx, hipGetLastError());
 

@@ -65,6 +65,13 @@ struct GenParams {
     uint32_t seed_lo, seed_hi;
     const uint4* lists;   // per-pixel candidate lists of the primary rays (k_primary_lists) or NULL
     float inv_npix, inv_nx, inv_band; // reciprocals rounded towards zero by 2^-22 (udiv_inv)
+    // Local pixel order.  tiles_per_row = 0: row-major (pl = lj * nx + i).  Else (nx a multiple of 8): the first
+    // tile_pixels = 64 * tiles_per_row * (rows / 8) pixels are enumerated in 8 x 8 tiles,
+    // pl = (tile_y * tiles_per_row + tile_x) * 64 + (lj & 7) * 8 + (i & 7) — 64 consecutive path slots, i.e. one wave of depth 0,
+    // are one 8 x 8 block of pixels instead of a 64 x 1 strip, which crosses fewer silhouettes — and the rows % 8 rows that are
+    // left (a shard of 135 rows) follow row-major.
+    uint32_t tiles_per_row, tile_pixels;
+    float inv_tpr;
 };
 
 // x / d for the slot arithmetic of gen_primary / path_key_of_slot (quotients below 2^21): a float product that never exceeds the true quotient
@@ -76,6 +83,25 @@ __device__ __forceinline__ uint32_t udiv_inv(uint32_t x, uint32_t d, float inv, 
     if (r >= d) ++qt, r -= d;
     rem = r;
     return qt;
+}
+// local pixel index -> (column i, local row lj), and back (k_finalize)
+__device__ __forceinline__ void pixel_of_local(const GenParams& gp, uint32_t pl, uint32_t& i, uint32_t& lj) {
+    if (gp.tiles_per_row == 0u) {
+        lj = udiv_inv(pl, gp.nx, gp.inv_nx, i);
+        return;
+    }
+    if (pl >= gp.tile_pixels) { // the last rows % 8 rows
+        lj = udiv_inv(pl, gp.nx, gp.inv_nx, i); // (tile_pixels is a multiple of nx: the same quotient as for a row-major frame)
+        return;
+    }
+    uint32_t tx;
+    const uint32_t ty = udiv_inv(pl >> 6, gp.tiles_per_row, gp.inv_tpr, tx);
+    i = tx * 8u + (pl & 7u);
+    lj = ty * 8u + ((pl >> 3) & 7u);
+}
+__host__ __device__ inline uint32_t local_of_pixel(uint32_t nx, uint32_t tiles_per_row, uint32_t tile_pixels, uint32_t i, uint32_t lj) {
+    if (tiles_per_row == 0u || lj * nx >= tile_pixels) return lj * nx + i;
+    return ((lj >> 3) * tiles_per_row + (i >> 3)) * 64u + (lj & 7u) * 8u + (i & 7u);
 }
 __device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t band, uint32_t count, uint32_t id) {
     if (count <= 1) return lj;
@@ -91,7 +117,8 @@ __device__ __forceinline__ void path_key_of_slot(const GenParams& gp, uint32_t s
     }
     uint32_t pl, i;
     const uint32_t s_local = udiv_inv(slot, gp.npix, gp.inv_npix, pl);
-    const uint32_t lj = udiv_inv(pl, gp.nx, gp.inv_nx, i);
+    uint32_t lj;
+    pixel_of_local(gp, pl, i, lj);
     uint32_t j = lj;
     if (gp.shard_count > 1u) {
         uint32_t rb;
@@ -107,7 +134,8 @@ __device__ __forceinline__ void gen_primary(const GenParams& gp, uint32_t idx, V
                                             uint32_t& pl) {
     uint32_t i;
     const uint32_t s_local = udiv_inv(idx, gp.npix, gp.inv_npix, pl); // pl = local pixel
-    const uint32_t lj = udiv_inv(pl, gp.nx, gp.inv_nx, i);
+    uint32_t lj;
+    pixel_of_local(gp, pl, i, lj);
     const uint32_t j = local_row_to_image_row(lj, gp.shard_band, gp.shard_count, gp.shard_id);
     const uint32_t samp = gp.s0 + s_local;
     Rng rng;
@@ -206,8 +234,8 @@ __global__ __launch_bounds__(256) void k_primary_lists(DevScene sc, GenParams gp
     const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
     const bool active = pl < gp.npix;
     const uint32_t plc = active ? pl : gp.npix - 1u;
-    const uint32_t lj = plc / gp.nx;
-    const uint32_t i = plc - lj * gp.nx;
+    uint32_t i, lj;
+    pixel_of_local(gp, plc, i, lj);
     const uint32_t j = local_row_to_image_row(lj, gp.shard_band, gp.shard_count, gp.shard_id);
     const V3 origin = v3(gp.cam_origin[0], gp.cam_origin[1], gp.cam_origin[2]);
     const V3 H = v3(gp.cam_horizontal[0], gp.cam_horizontal[1], gp.cam_horizontal[2]);
@@ -1215,11 +1243,13 @@ __global__ __launch_bounds__(256) void k_resolve(const float* __restrict__ rad, 
 // main.rs:98-105,127.  out_f32: linear mean (before gamma), local row order; out_u8: gamma 2,
 // *255.99 saturating cast, rows flipped.  sqrtf is the correctly rounded value of powf(x, 0.5).
 __global__ __launch_bounds__(256) void k_finalize(const float* __restrict__ acc, float* __restrict__ out_f32,
-                                                  uint8_t* __restrict__ out_u8, uint32_t nx, uint32_t rows, uint32_t spp) {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+                                                  uint8_t* __restrict__ out_u8, uint32_t nx, uint32_t rows, uint32_t spp,
+                                                  uint32_t tiles_per_row, uint32_t tile_pixels) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x; // output pixel, row-major in the shard's local rows
     if (p >= nx * rows) return;
     const float fs = (float)spp;
-    float c[3] = {acc[3 * (size_t)p] / fs, acc[3 * (size_t)p + 1] / fs, acc[3 * (size_t)p + 2] / fs};
+    const size_t ap = local_of_pixel(nx, tiles_per_row, tile_pixels, p % nx, p / nx); // where the path slots keep this pixel (GenParams)
+    float c[3] = {acc[3 * ap] / fs, acc[3 * ap + 1] / fs, acc[3 * ap + 2] / fs};
     if (out_f32) {
         out_f32[3 * (size_t)p] = c[0], out_f32[3 * (size_t)p + 1] = c[1], out_f32[3 * (size_t)p + 2] = c[2];
     }

@@ -277,6 +277,25 @@ def test_tall_narrow_frame_up_to_the_row_limit(rt, orc, renderer):
     assert part.shape[0] == 1 << 20
 
 
+def test_tile_order_of_path_slots_does_not_change_images(rt, renderer, monkeypatch):
+    """Path slots enumerate the pixels of a shard in 8 x 8 tiles (one wave of depth 0 = one tile) when nx is a multiple of 8 —
+    the last rows % 8 rows and other widths in rows (rt_kernels.h GenParams::tiles_per_row).  Keys, candidate lists, the sample sum and
+    the output image are functions of the pixel, not of its slot: frames, RGB8 and ray counts are the same bit for bit either
+    way — full frame, sharded (whole tiles per band and not), with slices, on a sphere-only and on a general scene."""
+    for name, nx, ny in (("sphere_scene", 320, 181), ("cornell_box", 96, 96)):  # 181 rows: 22 tile rows + 5 rows
+        scene = rt.Scene.build(name, nx / ny)
+        renderer.upload(scene)
+        for kw in ({}, {"spp_slice": 3}, {"shard_band": 8, "shard_count": 3, "shard_id": 1}, {"shard_band": 4, "shard_count": 2, "shard_id": 0}):
+            p = rt.make_params(nx, ny, 6, max_depth=12, seed=3, **kw)
+            monkeypatch.setenv("RTOW_ROW_MAJOR", "1")
+            rows, rows8, sr = renderer.render(scene.camera, p, want_rgb8=True)
+            monkeypatch.setenv("RTOW_ROW_MAJOR", "0")
+            tiles, tiles8, st = renderer.render(scene.camera, p, want_rgb8=True)
+            monkeypatch.delenv("RTOW_ROW_MAJOR")
+            assert np.array_equal(rows.view(np.uint32), tiles.view(np.uint32)) and np.array_equal(rows8, tiles8), (name, kw)
+            assert sr.n_rays == st.n_rays and list(sr.rays_per_depth) == list(st.rays_per_depth)
+
+
 def test_render_sharding_is_bit_invariant(rt, renderer):
     scene = rt.Scene.build("sphere_scene", 16 / 9)
     renderer.upload(scene)
