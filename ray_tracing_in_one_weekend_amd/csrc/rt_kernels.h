@@ -994,9 +994,10 @@ __host__ __device__ inline size_t shade_lds_bytes(uint32_t n_entries, uint32_t n
 }
 template <bool PERLIN_LDS, bool GEN, bool RECTS>
 #ifndef RT_GEN_WAVES
-#define RT_GEN_WAVES 6 // waves per SIMD the depth-0 instantiations are compiled for (80 VGPR, 8 B of scratch).  Round 2: 4 / 5 / 6 no
-                       // difference; with round 3's cheaper draws 6 is 2.4-2.7 % faster at depth 0 on the sphere scenes, 4 % on
-                       // earth_env_scene, +-1 % on the general ones (profiles/round3/ab_gen_waves.txt)
+#define RT_GEN_WAVES 4 // waves per SIMD the depth-0 instantiations are compiled for (98 VGPR: 5 fit).  Round 2: 4 / 5 / 6 no difference.
+                       // Round 3 (cheaper draws): alone on the chip, 6 (80 VGPR, 8 B of scratch) is 2.4-2.7 % faster at depth 0 on the
+                       // sphere scenes; in the production frame, where the two chains overlap, its dispatches last 12.3 ms instead
+                       // of 10.3 and the frame takes the same 56.5 ms (profiles/round3/ab_gen_waves.txt): left at 4
 #endif
 __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : 4) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
                                                const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,

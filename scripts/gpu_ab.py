@@ -38,7 +38,7 @@ for k, spec in enumerate(libs):  # "lib.so" or "lib.so@ENV=VALUE[,ENV2=VALUE2]":
     for name, _ in kv:
         os.environ.pop(name, None)
     rends.append(r)
-p = rt.make_params(1920, 1080, spp, max_depth=50, flags=rt._ffi.FLAG_TIME_DEPTHS)
+p = rt.make_params(1920, 1080, spp, max_depth=50, flags=int(os.environ.get("RTOW_AB_FLAGS", rt._ffi.FLAG_TIME_DEPTHS)))  # 0: the production two-chain frame (device ms only)
 res = {i: [] for i in range(len(libs))}
 per_depth = {i: [] for i in range(len(libs))}
 for it in range(rounds + 1):
