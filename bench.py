@@ -2,8 +2,9 @@
 """bench.py — headline benchmark of the MI355X wavefront path tracer.
 
 Metric (BASELINE.json): Mray/s (primary + secondary) on demo_scene.rs `sphere_scene`
-("random-spheres", 533 spheres) at 1920x1080, 256 spp, max depth 50 — config 2, the default.
-    --config 3   sphere_scene 3840x2160, 1024 spp            (BASELINE.json configs[2])
+("random-spheres", 533 spheres) at 1920x1080, 256 spp, max depth 50 — config 2, the default on ONE GPU.
+    --config 3   sphere_scene 3840x2160, 1024 spp            (BASELINE.json configs[2]: the frame north_star names for the
+                                                              8 GPUs of a node — the default when --gpus N > 1, strong scaling)
     --config 4   earth_env_scene 1920x1080, 512 spp           (configs[3]: ImageTex + environment sky)
     --config 5   pbr_sweep_scene 1920x1080, 4096 spp          (configs[4]: pbr.rs sweep)
 
@@ -13,13 +14,17 @@ HBM.  With N > 1 ranks (one process per GPU, torch.distributed, backend nccl == 
 sharded in interleaved bands of 8 rows and each step ends with the all_gather of the band buffers.
     --scaling weak    (default for config 2) per-GPU work fixed: every rank renders (ny/N rows) x nx x spp*N samples
     --scaling strong  (default for configs 3-5) the stated frame split over the N ranks
+With N > 1 and no --config the line is config 3 strong, and a short config-2 weak leg (2 steps) rides along under "also";
+the line carries the gather time per step ("gather_ms", HIP events around the all_gather + de-interleave) and the trace-step
+HBM fraction of every rank ("roofline.per_rank").
 
 `python bench.py --gpus N` without a torchrun environment starts the N rank processes itself (a child
 `python -m torch.distributed.run` started BEFORE this process touches a GPU) and relays rank 0's JSON line.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) including
   "roofline":     trace-step algorithmic HBM bytes / its device time (HIP events on the launch stream)
-  "cpu_baseline": the CPU oracle in reference (stream) order, all host cores, bounded sample
+  "cpu_baseline": the CPU oracle in reference (stream) order, all host cores, bounded sample; built -O3 -march=native on
+                  the box it is timed on when g++ is there (BASELINE.md's recipe), else the prebuilt -march=x86-64-v2 library
 """
 import argparse
 import json
@@ -106,11 +111,37 @@ def usable_cores():
     return max(1, n)
 
 
+def native_oracle():
+    """BASELINE.md times the CPU reference as `-O3 -march=native`; the oracle that travels with the snapshot is built
+    -march=x86-64-v2 so that it runs on any host.  For the timed baseline the same source is compiled once more ON the box
+    that times it (oracle/_native/, git- and gpurun-ignored scratch; ~20 s of g++).  -mno-avx... is not needed: native code
+    and libm's routines agree on the vector state of the machine they were both chosen for.  Returns (flags, ok)."""
+    import shutil
+    from oracle import binding as orc
+    portable = "-O3 -march=x86-64-v2 -ffp-contract=off (prebuilt, portable across hosts)"
+    cxx = shutil.which("g++")
+    if not cxx:
+        return portable, False
+    odir = os.path.join(ROOT, "oracle")
+    out_dir = os.path.join(odir, "_native")
+    out = os.path.join(out_dir, "liboracle_native.so")
+    flags = ["-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC", "-pthread"]
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.run([cxx] + flags + ["-shared", "-o", out, os.path.join(odir, "oracle.cpp")], check=True, timeout=120,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        orc.load(out)
+        return " ".join(flags[:4]) + " (compiled on this host)", True
+    except Exception:  # noqa: BLE001 (no compiler budget, read-only tree, ...: the portable library is the baseline then)
+        return portable, False
+
+
 def cpu_baseline(rt, scene, name, nx, ny, max_depth, budget_s=15.0):
     """Times the oracle (kind "port": C++ restatement of the reference, stream RNG order, BVH,
     one worker per host core like threadpool's default) on a bounded sample of the workload:
     the same frame at reduced spp (Mray/s does not depend on spp)."""
     from oracle import binding as orc
+    flags, _ = native_oracle()
     cores = usable_cores()
     opts = orc.options(rng_mode=orc.RNG_STREAM, estimator=orc.EST_RECURSIVE, accel=orc.ACCEL_BVH,
                        n_threads=cores, bvh_seed=1995, bvh_skip_perlin=1)
@@ -123,7 +154,7 @@ def cpu_baseline(rt, scene, name, nx, ny, max_depth, budget_s=15.0):
     t0 = time.time()
     _, _, st = orc.render(scene.flat_ptr, scene.camera, p, opts)
     dt = max(time.time() - t0, 1e-6)
-    return {"value": round(st.n_rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
+    return {"value": round(st.n_rays / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port", "flags": flags,
             "sample": f"{name} {nx}x{ny}, {spp} spp, max_depth {max_depth}, {st.n_rays} rays in {dt:.1f} s "
                       f"(oracle stream mode: per-column xoshiro256++, recursive estimator, BVH)"}
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 7u
+#define RT_ABI_VERSION 8u
 
 /* error codes */
 #define RT_OK 0
@@ -285,6 +285,14 @@ uint32_t rt_shard_row_to_image_row(uint32_t local_row, uint32_t shard_band, uint
 int rt_render(RtCtx* ctx, const RtCamera* cam, const RtParams* params, float* out_rgb_f32,
               uint8_t* out_rgb8, RtStats* stats);
 
+/* Pinned (page-locked) host memory for the two output images.  rt_render() writes a destination allocated here — or any
+ * memory the caller has registered with the HIP runtime — by asynchronous copies at PCIe rate behind the last kernel; a
+ * pageable destination (a plain Vec / malloc) works too and costs a staged copy (~3 ms instead of ~0.6 ms for a
+ * 1920 x 1080 frame).  This is what a host that replaces main.rs:109-128 (the receive loop that fills the ImageBuffer)
+ * would allocate its frame in.  NULL on failure. */
+void* rt_host_alloc(size_t bytes);
+void rt_host_free(void* p);
+
 /*
  * Same, but the f32 framebuffer stays in HBM: `d_out_rgb_f32` is a DEVICE pointer to
  * rows_local*nx*3 floats (e.g. the storage of a tensor that RCCL will gather).  `stream`
@@ -347,6 +355,51 @@ int rt_multi_render(RtMulti* m, const RtCamera* cam, const RtParams* params, flo
  * either may be NULL).  `stream` as in rt_render_device. */
 int rt_deinterleave_bands(RtCtx* ctx, const void* d_gathered, uint32_t nx, uint32_t ny, uint32_t band, uint32_t n_shards,
                           void* d_out_rgb_f32, void* d_out_rgb8, void* stream);
+
+/* -- debug / tuning options (test hooks) ---------------------------------------------------------------------------
+ * Per context (not per process: the library reads no environment variable); EVERY setting renders the same bits — the
+ * options select between equivalent search structures, placements and orders so that tests can hold them against each
+ * other, and so that measurements can vary one thing.  0 is the library's own choice for every option.  Options marked
+ * (upload) take effect at the next rt_scene_upload, the others at the next render. */
+enum RtDebugOption {
+    RT_OPT_TREE_PLACEMENT = 0,        /* (upload) 1: the BVH is read through L2 even when it would fit LDS */
+    RT_OPT_PRIMARY_LISTS = 1,         /* 1: no per-pixel candidate lists, depth 0 walks the tree */
+    RT_OPT_PIXEL_ORDER = 2,           /* 1: path slots enumerate pixels row by row, 2: in 8 x 8 tiles wherever the frame allows */
+    RT_OPT_TEXEL_POOL = 3,            /* (upload) 1: float4 texel pool even when every texel is k/255 */
+    RT_OPT_GRID = 4,                  /* 1: no uniform grid, sphere-only scenes walk the tree at every depth */
+    RT_OPT_GRID_CELL = 5,             /* (upload) grid cell edge in 1/1000 of the median sphere diameter */
+    RT_OPT_CHAINS = 6,                /* 1: one chain of launches per slice, 2: two shard groups on two streams */
+    RT_OPT_GENERAL_KERNELS = 7,       /* (upload) 1: the general-scene kernel instantiations on a sphere-only scene */
+    RT_OPT_GENERAL_LDS = 8,           /* (upload) 1: wrapper / medium tables stay in HBM */
+    RT_OPT_QUEUE_SHARDS = 9,          /* n: queue shards (default 8 per CU) */
+    RT_OPT_ISECT_WORKGROUPS = 10,     /* n: closest-hit workgroups per launch */
+    RT_OPT_MATERIALISE_PRIMARIES = 11,/* 1: primary rays are written to the queue by their own kernel instead of regenerated */
+    RT_OPT__COUNT = 12
+};
+int rt_debug_set_option(RtCtx* ctx, uint32_t option, uint32_t value);
+int rt_debug_get_option(const RtCtx* ctx, uint32_t option, uint32_t* value);
+
+/* What rt_scene_upload built for the closest-hit search of the uploaded scene. */
+typedef struct RtSceneInfo {
+    uint32_t n_entries;            /* world entries: primitives that are not a medium boundary + media */
+    uint32_t n_tree_nodes, tree_depth;
+    uint32_t tree_in_lds;          /* 1: the BVH4 is staged in LDS, 0: read through L2 */
+    uint32_t general_kernels;      /* 1: rectangles / wrappers / media (or forced) */
+    uint32_t closest_hit_lds_bytes;
+    uint32_t grid;                 /* 1: depth >= 1 walks a uniform grid (sphere-only scenes, csrc/rt_grid.h) */
+    uint32_t grid_cells[3];
+    uint32_t grid_refs;            /* sphere references in the cell lists */
+    uint32_t grid_always;          /* large spheres tested for every ray */
+    uint32_t grid_lds_bytes;
+    float grid_cell_size[3];
+} RtSceneInfo;
+int rt_debug_scene_info(const RtCtx* ctx, RtSceneInfo* info);
+
+#ifdef RT_PROFILE_LANES
+/* Diagnostic builds only (-DRT_PROFILE_LANES; absent from the product library): the lane-occupancy counters of
+ * csrc/rt_kernels.h, optionally reset after reading. */
+int rt_debug_lane_stats(unsigned long long* out24, int reset);
+#endif
 
 /* -- single-bounce evaluation (test hook) --------------------------------------------------
  * Runs ONE closest-hit + shade step (main.rs:44-58 for one depth) over `n` caller-given

@@ -97,10 +97,32 @@ class RtBounceIO(C.Structure):
 RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32)
 
 MULTI_COPY_GATHER = 1  # RT_MULTI_COPY_GATHER (rt_multi_create_ex)
-EXPECTED_ABI = 7  # RT_ABI_VERSION the struct layouts and prototypes below were written for
+# enum RtDebugOption (rt_debug_set_option): per context, every setting renders the same bits
+(OPT_TREE_PLACEMENT, OPT_PRIMARY_LISTS, OPT_PIXEL_ORDER, OPT_TEXEL_POOL, OPT_GRID, OPT_GRID_CELL, OPT_CHAINS,
+ OPT_GENERAL_KERNELS, OPT_GENERAL_LDS, OPT_QUEUE_SHARDS, OPT_ISECT_WORKGROUPS, OPT_MATERIALISE_PRIMARIES) = range(12)
+OPT_NAMES = {"tree_placement": OPT_TREE_PLACEMENT, "primary_lists": OPT_PRIMARY_LISTS, "pixel_order": OPT_PIXEL_ORDER,
+             "texel_pool": OPT_TEXEL_POOL, "grid": OPT_GRID, "grid_cell": OPT_GRID_CELL, "chains": OPT_CHAINS,
+             "general_kernels": OPT_GENERAL_KERNELS, "general_lds": OPT_GENERAL_LDS, "queue_shards": OPT_QUEUE_SHARDS,
+             "isect_workgroups": OPT_ISECT_WORKGROUPS, "materialise_primaries": OPT_MATERIALISE_PRIMARIES}
+
+
+class RtSceneInfo(C.Structure):
+    _fields_ = [("n_entries", C.c_uint32), ("n_tree_nodes", C.c_uint32), ("tree_depth", C.c_uint32), ("tree_in_lds", C.c_uint32),
+                ("general_kernels", C.c_uint32), ("closest_hit_lds_bytes", C.c_uint32), ("grid", C.c_uint32),
+                ("grid_cells", C.c_uint32 * 3), ("grid_refs", C.c_uint32), ("grid_always", C.c_uint32),
+                ("grid_lds_bytes", C.c_uint32), ("grid_cell_size", C.c_float * 3)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("grid_cells", "grid_cell_size")}
+        d["grid_cells"], d["grid_cell_size"] = list(self.grid_cells), [float(x) for x in self.grid_cell_size]
+        return d
+
+
+EXPECTED_ABI = 8  # RT_ABI_VERSION the struct layouts and prototypes below were written for
 GPU_SYMBOLS = ["rt_abi_version", "rt_build_id", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
                "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce",
-               "rt_get_depth_timings", "rt_set_progress", "rt_multi_create", "rt_multi_create_ex", "rt_multi_destroy", "rt_multi_device_count",
+               "rt_get_depth_timings", "rt_set_progress", "rt_host_alloc", "rt_host_free", "rt_debug_set_option", "rt_debug_get_option",
+               "rt_debug_scene_info", "rt_multi_create", "rt_multi_create_ex", "rt_multi_destroy", "rt_multi_device_count",
                "rt_multi_last_error", "rt_multi_scene_upload", "rt_multi_render", "rt_deinterleave_bands"]
 HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
                 "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
@@ -153,6 +175,16 @@ def load_gpu_library():
     lib.rt_debug_bounce.restype = C.c_int
     lib.rt_set_progress.argtypes = [vp, RtProgressFn, vp]
     lib.rt_set_progress.restype = C.c_int
+    lib.rt_host_alloc.argtypes = [C.c_size_t]
+    lib.rt_host_alloc.restype = vp
+    lib.rt_host_free.argtypes = [vp]
+    lib.rt_host_free.restype = None
+    lib.rt_debug_set_option.argtypes = [vp, C.c_uint32, C.c_uint32]
+    lib.rt_debug_set_option.restype = C.c_int
+    lib.rt_debug_get_option.argtypes = [vp, C.c_uint32, _u32]
+    lib.rt_debug_get_option.restype = C.c_int
+    lib.rt_debug_scene_info.argtypes = [vp, C.POINTER(RtSceneInfo)]
+    lib.rt_debug_scene_info.restype = C.c_int
     lib.rt_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     lib.rt_multi_create.restype = C.c_int
     lib.rt_multi_create_ex.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_uint32, C.POINTER(vp)]

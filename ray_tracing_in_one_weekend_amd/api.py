@@ -212,14 +212,62 @@ class Renderer:
         if rc != 0:
             self._raise("rt_scene_upload", rc)
 
+    def set_option(self, option, value):
+        """rt_debug_set_option: `option` an _ffi.OPT_* number or its lower-case name.  Per context; every setting renders the
+        same bits (they select between equivalent search structures / placements / orders).  Upload-time options
+        (tree_placement, texel_pool, grid_cell, general_lds) take effect at the next upload()."""
+        opt = _ffi.OPT_NAMES[option] if isinstance(option, str) else int(option)
+        rc = self._lib.rt_debug_set_option(self._ctx, opt, int(value))
+        if rc != 0:
+            self._raise("rt_debug_set_option", rc)
+
+    def get_option(self, option):
+        opt = _ffi.OPT_NAMES[option] if isinstance(option, str) else int(option)
+        v = C.c_uint32()
+        rc = self._lib.rt_debug_get_option(self._ctx, opt, C.byref(v))
+        if rc != 0:
+            self._raise("rt_debug_get_option", rc)
+        return v.value
+
+    def scene_info(self):
+        """rt_debug_scene_info as a dict: what upload() built for the closest-hit search (tree placement, grid or not)."""
+        info = _ffi.RtSceneInfo()
+        rc = self._lib.rt_debug_scene_info(self._ctx, C.byref(info))
+        if rc != 0:
+            self._raise("rt_debug_scene_info", rc)
+        return info.as_dict()
+
     def shard_rows(self, params):
         return self._lib.rt_shard_rows(params.ny, params.shard_band or 1, params.shard_count, params.shard_id)
 
-    def render(self, camera, params, want_rgb8=False):
-        """Returns (f32 image [rows, nx, 3] (row 0 = bottom), rgb8 or None, RtStats)."""
+    def _pinned(self, shape, dtype):
+        """A numpy array over rt_host_alloc'ed (page-locked) memory, kept and reused by this Renderer: rt_render writes it
+        by asynchronous copies at PCIe rate (what a host replacing main.rs:109-128 would allocate its frame in)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        key = np.dtype(dtype).char
+        if not hasattr(self, "_pin"):
+            self._pin = {}
+        ptr, size = self._pin.get(key, (None, 0))
+        if size < n:
+            if ptr:
+                self._lib.rt_host_free(ptr)
+            ptr = self._lib.rt_host_alloc(max(n, 1))
+            if not ptr:
+                raise RtError("rt_host_alloc failed")
+            self._pin[key] = (ptr, n)
+        buf = (C.c_char * max(n, 1)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def render(self, camera, params, want_rgb8=False, pinned=False):
+        """Returns (f32 image [rows, nx, 3] (row 0 = bottom), rgb8 or None, RtStats).  pinned=True: the arrays are views of
+        this Renderer's page-locked staging buffers (valid until the next pinned render or close())."""
         rows = self.shard_rows(params)
-        img = np.zeros((rows, params.nx, 3), dtype=np.float32)
-        rgb8 = np.zeros((rows, params.nx, 3), dtype=np.uint8) if want_rgb8 else None
+        if pinned:
+            img = self._pinned((rows, params.nx, 3), np.float32)
+            rgb8 = self._pinned((rows, params.nx, 3), np.uint8) if want_rgb8 else None
+        else:
+            img = np.zeros((rows, params.nx, 3), dtype=np.float32)
+            rgb8 = np.zeros((rows, params.nx, 3), dtype=np.uint8) if want_rgb8 else None
         stats = RtStats()
         rc = self._lib.rt_render(self._ctx, C.byref(camera), C.byref(params),
                                  img.ctypes.data_as(C.POINTER(C.c_float)),
@@ -297,6 +345,10 @@ class Renderer:
         if self._ctx:
             self._lib.rt_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
+        for ptr, _ in getattr(self, "_pin", {}).values():
+            if ptr:
+                self._lib.rt_host_free(ptr)
+        self._pin = {}
 
     def __del__(self):
         try:

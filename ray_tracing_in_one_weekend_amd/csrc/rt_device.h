@@ -129,12 +129,6 @@ __device__ __forceinline__ void path_key(uint64_t seed, uint32_t pix, uint32_t s
     k0 = fmix32(a + samp * 0x9E3779B9u + s_hi);
     k1 = fmix32((a ^ 0xA511E9B3u) + samp * 0xC2B2AE3Du);
 }
-// RT_WHATIF (throw-away builds that price one thing at a time; WRONG images, never in the product library):
-//   1: every draw costs TWO mixing rounds (rounds 1-2)  2: the Perlin turbulence returns a constant
-//   4: random_in_unit_sphere accepts its first try     8: path_key_of_slot is free (key = slot)
-#ifndef RT_WHATIF
-#define RT_WHATIF 0
-#endif
 // `w` is the Weyl term ctr * 0x9E3779B9 of the NEXT draw, advanced by an addition: the same values as the product, and one
 // quarter-rate integer multiply less per draw (two are left, in mix32).
 struct Rng {
@@ -142,7 +136,7 @@ struct Rng {
     __device__ __forceinline__ Rng() {}
     __device__ __forceinline__ Rng(uint32_t k0_, uint32_t k1_, uint32_t ctr) : k0(k0_), k1(k1_), w(ctr * 0x9E3779B9u) {}
     __device__ __forceinline__ float next() {
-        uint32_t r = (RT_WHATIF & 1) ? fmix32(fmix32(k0 ^ w) + k1) : mix32((k0 ^ w) + k1);
+        uint32_t r = mix32((k0 ^ w) + k1);
         w += 0x9E3779B9u;
         return (float)(r >> 8) * (1.0f / 16777216.0f);
     }
@@ -162,7 +156,7 @@ __device__ __forceinline__ V3 random_in_unit_sphere(Rng& rng) { // math.rs:17-37
         float y = rng.next();
         float z = rng.next();
         V3 v = v3(x, y, z) * (1.0f - -1.0f) + -1.0f;
-        if ((RT_WHATIF & 4) || length_squared(v) < 1.0f) return v;
+        if (length_squared(v) < 1.0f) return v;
     }
 }
 __device__ __forceinline__ V3 random_on_hemisphere(Rng& rng, V3 n) { // math.rs:43-53
@@ -331,7 +325,6 @@ __device__ inline float perlin_noise(const PerlinTables& pt, uint32_t set, V3 p)
     return accum;
 }
 __device__ inline float perlin_turb(const PerlinTables& pt, uint32_t set, V3 p) { // texture.rs:115-124
-    if (RT_WHATIF & 2) return p.x;
     float accum = 0.0f;
     float w = 1.0f;
     for (int it = 0; it < 7; ++it) {
@@ -477,6 +470,14 @@ __device__ __forceinline__ bool sphere_root(float4 g, V3 o, V3 d, float a, float
     V3 oc = o - v3(g.x, g.y, g.z);
     float half_b = dot(oc, d);
     float c = length_squared(oc) - g.w * g.w;
+    // A sphere behind an origin outside it cannot be hit, and the reference's arithmetic agrees to the bit (so the square root
+    // and the two divisions are skipped without changing any result): with c > 0 and a > 0 the discriminant is
+    // fl(fl(hb^2) - fl(a c)) <= fl(hb^2), so sqrtd <= fl(sqrt(fl(hb^2))) = hb (correctly rounded sqrt of a rounded square gives
+    // the number back; an overflowing hb^2 makes both roots infinite), both numerators -hb -+ sqrtd are <= 0 and both roots fail
+    // `root < t_min` for any t_min > 0.  That is every ray leaving the surface it was scattered from (offset_hit_point puts the
+    // origin 256 ulps outside, math.rs:144-156) — the r = 1000 ground for most secondary rays — and about half of the spheres
+    // listed around a ray's origin.  (ConstantMedium's boundary searches pass t_min = -inf and take the plain path.)
+    if (t_min > 0.0f && half_b > 0.0f && c > 0.0f) return false;
     float discriminant = half_b * half_b - a * c;
     if (discriminant < 0.0f) return false;
     float sqrtd = sqrtf(discriminant);

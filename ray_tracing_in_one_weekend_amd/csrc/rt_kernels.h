@@ -111,10 +111,6 @@ __device__ __forceinline__ uint32_t local_row_to_image_row(uint32_t lj, uint32_t
 // RNG key of the path in slot `slot` of the slice: the inverse of slot = s_local * npix + pixel_local, then path_key
 // exactly as gen_primary computes it.
 __device__ __forceinline__ void path_key_of_slot(const GenParams& gp, uint32_t slot, uint32_t& k0, uint32_t& k1) {
-    if (RT_WHATIF & 8) {
-        k0 = slot, k1 = slot ^ 0x9E3779B9u;
-        return;
-    }
     uint32_t pl, i;
     const uint32_t s_local = udiv_inv(slot, gp.npix, gp.inv_npix, pl);
     uint32_t lj;
@@ -1294,76 +1290,6 @@ __global__ __launch_bounds__(256) void k_debug_fill(GenParams gp, Queue q, const
     q.c[pos] = make_float2(1.0f, 1.0f);
 }
 
-#ifdef RT_WHATIF_REORDER
-// What-if builds only (scripts/gpu_r3_probe.py; never in the product library): reorders the rays of every shard by a
-// coherence key — direction octant and / or a Morton cell of the origin — in an UNTIMED pass in front of k_intersect, to
-// price what secondary-ray coherence could buy before anything is built for it.  Closest hits do not depend on the order
-// (winner rule, hitable.rs:117-132) and hit records travel by queue position, so frames stay bit-identical.
-struct ReorderParams {
-    uint32_t cap;
-    uint32_t oct;   // 1: the direction octant is part of the key
-    uint32_t nb;    // bits per axis of the origin cell (0: none)
-    uint32_t dims;  // 3: x, y, z cells; 2: x, z cells
-    uint32_t order; // 0: octant-major, 1: cell-major
-    float bx, by, bz, sx, sy, sz; // cell = clamp((o - b) * s, 0, 2^nb - 1)
-};
-__device__ __forceinline__ uint32_t reorder_key(const ReorderParams& rp, float4 ra, float4 rb) {
-    const uint32_t oct = rp.oct ? ((rb.x < 0.0f ? 1u : 0u) | (rb.y < 0.0f ? 2u : 0u) | (rb.z < 0.0f ? 4u : 0u)) : 0u;
-    uint32_t cell = 0u;
-    if (rp.nb) {
-        const float hi = (float)((1u << rp.nb) - 1u);
-        const uint32_t cx = (uint32_t)fminf(fmaxf((ra.x - rp.bx) * rp.sx, 0.0f), hi);
-        const uint32_t cy = (uint32_t)fminf(fmaxf((ra.y - rp.by) * rp.sy, 0.0f), hi);
-        const uint32_t cz = (uint32_t)fminf(fmaxf((ra.z - rp.bz) * rp.sz, 0.0f), hi);
-        for (uint32_t b = 0; b < rp.nb; ++b) { // Morton interleave, low bits first
-            if (rp.dims == 3u) cell |= (((cx >> b) & 1u) << (3u * b)) | (((cy >> b) & 1u) << (3u * b + 1u)) | (((cz >> b) & 1u) << (3u * b + 2u));
-            else cell |= (((cx >> b) & 1u) << (2u * b)) | (((cz >> b) & 1u) << (2u * b + 1u));
-        }
-    }
-    const uint32_t cell_bits = rp.dims * rp.nb;
-    return rp.order ? (cell << (rp.oct ? 3u : 0u)) | oct : (oct << cell_bits) | cell;
-}
-#define RT_REORDER_KEYS 4096u
-__global__ __launch_bounds__(1024) void k_whatif_reorder(Queue q, Queue tmp, const uint32_t* __restrict__ counts, ReorderParams rp) {
-    __shared__ uint32_t s_off[RT_REORDER_KEYS];
-    __shared__ uint32_t s_scan[1024];
-    const uint32_t shard = blockIdx.x;
-    const uint32_t n = counts[shard];
-    if (n == 0) return;
-    const size_t base = (size_t)shard * rp.cap;
-    for (uint32_t k = threadIdx.x; k < RT_REORDER_KEYS; k += 1024u) s_off[k] = 0u;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024u)
-        atomicAdd(&s_off[reorder_key(rp, q.a[RT_QSTRIDE * (base + i)], q.b[RT_QSTRIDE * (base + i)])], 1u);
-    __syncthreads();
-    // exclusive scan over the 4096 key counts: 4 per thread, Hillis-Steele over the 1024 partial sums
-    uint32_t c[4], sum = 0;
-    for (int k = 0; k < 4; ++k) c[k] = s_off[4u * threadIdx.x + k], sum += c[k];
-    s_scan[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_scan[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_scan[threadIdx.x] - sum;
-    for (int k = 0; k < 4; ++k) s_off[4u * threadIdx.x + k] = run, run += c[k];
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
-        const float4 ra = q.a[RT_QSTRIDE * (base + i)], rb = q.b[RT_QSTRIDE * (base + i)];
-        const float2 rc = q.c[base + i];
-        const uint32_t dst = atomicAdd(&s_off[reorder_key(rp, ra, rb)], 1u);
-        tmp.a[RT_QSTRIDE * (base + dst)] = ra, tmp.b[RT_QSTRIDE * (base + dst)] = rb, tmp.c[base + dst] = rc;
-    }
-    __threadfence();
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
-        q.a[RT_QSTRIDE * (base + i)] = tmp.a[RT_QSTRIDE * (base + i)], q.b[RT_QSTRIDE * (base + i)] = tmp.b[RT_QSTRIDE * (base + i)];
-        q.c[base + i] = tmp.c[base + i];
-    }
-}
-#endif
 
 // Test hook: one bounce for caller-given rays, no queues (rt_debug_bounce).
 template <int BLOCK, bool USE_BVH, bool LDS_NODES>

@@ -1,5 +1,7 @@
 """Interleaved A/B of library builds in ONE process on ONE device (cdna guide rule 24):
-python scripts/gpu_ab.py <spp> <rounds> libA.so libB.so[@ENV=VALUE] ...   -> median isect/shade/total ms per variant
+python scripts/gpu_ab.py <spp> <rounds> libA.so libB.so[@option=value,...] ...   -> median isect/shade/total ms per variant
+(options: the names of rt_debug_set_option, _ffi.OPT_NAMES, set on that variant's context before its scene is uploaded;
+ "-" as the library = the in-tree librtow_mi355x.so)
 (RTOW_SCENE=name picks the scene, RTOW_AB_DEPTHS=N adds the per-depth split of the first N depths)
 
 Position bias: the variant listed FIRST has been seen to read up to 0.5 ms (2-3 %) high on k_shade with two identical
@@ -9,8 +11,7 @@ difference only when it exceeds the spread between the identical copies.
 Noise floor per scene: on cornell_box the SAME binary read k_shade 24.77 ms first and 25.80 ms last in one run (4 %,
 gpurun_out/r2/ab_align.txt), and two builds with identical k_shade source differed by as much; on sphere_scene identical
 binaries agree to ~1 %.  Judge a k_shade difference on cornell_box or final_scene only against that spread.  A same-binary
-switch (an environment variable read per render, as RTOW_FLOAT_TEXELS or RTOW_ONE_STREAM) alternated several times is the
-better experiment whenever one is possible.  (-falign-loops=64 / 128: no effect on any scene.)"""
+switch (an rt_debug_set_option of one context, alternated several times) is the better experiment whenever one is possible.  (-falign-loops=64 / 128: no effect on any scene.)"""
 import ctypes
 import os
 import statistics
@@ -25,18 +26,17 @@ libs = sys.argv[3:]
 rt.register_default_images()
 scene = rt.Scene.build(os.environ.get("RTOW_SCENE", "sphere_scene"), 16 / 9)
 rends = []
-for k, spec in enumerate(libs):  # "lib.so" or "lib.so@ENV=VALUE[,ENV2=VALUE2]": variables set while this variant's scene is uploaded
-    path, _, envs = spec.partition("@")
-    libs[k] = os.path.basename(path) + ("@" + envs if envs else "")
+default_lib = _ffi.GPU_LIB_PATH
+for k, spec in enumerate(libs):  # "lib.so" or "lib.so@option=value[,option2=value2]"
+    path, _, opts = spec.partition("@")
+    path = default_lib if path == "-" else path
+    libs[k] = os.path.basename(path) + ("@" + opts if opts else "")
     _ffi._gpu_lib = None
     _ffi.GPU_LIB_PATH = path
-    kv = [e.split("=", 1) for e in envs.split(",") if e]
-    for name, val in kv:
-        os.environ[name] = val
     r = rt.Renderer(0)
+    for name, val in (e.split("=", 1) for e in opts.split(",") if e):
+        r.set_option(name, int(val))
     r.upload(scene)
-    for name, _ in kv:
-        os.environ.pop(name, None)
     rends.append(r)
 p = rt.make_params(1920, 1080, spp, max_depth=50, flags=int(os.environ.get("RTOW_AB_FLAGS", rt._ffi.FLAG_TIME_DEPTHS)))  # 0: the production two-chain frame (device ms only)
 res = {i: [] for i in range(len(libs))}
@@ -50,7 +50,7 @@ for it in range(rounds + 1):
             per_depth[i].append((a.copy(), b.copy()))
 for i, path in enumerate(libs):
     a = statistics.median(x[0] for x in res[i]); b = statistics.median(x[1] for x in res[i]); t = statistics.median(x[2] for x in res[i])
-    print(f"{os.path.basename(path):40s} isect {a:7.2f} ms  shade {b:7.2f} ms  device {t:7.2f} ms  rays {res[i][0][3]}  "
+    print(f"{path:40s} isect {a:7.2f} ms  shade {b:7.2f} ms  device {t:7.2f} ms  rays {res[i][0][3]}  "
           f"-> {res[i][0][3] / t / 1e3:8.0f} Mray/s")
 # RTOW_AB_DEPTHS=N: the first N depths (median ms of k_intersect / k_shade per variant) and the rest as one line
 nd = int(os.environ.get("RTOW_AB_DEPTHS", "0"))

@@ -43,3 +43,15 @@ def renderer(rt):
     r = rt.Renderer(0)
     yield r
     r.close()
+
+
+@pytest.fixture(autouse=True)
+def _default_options(request):
+    """The session's Renderer goes back to the library's own choices after every test (rt_debug_set_option is per context,
+    and a test that fails between setting and resetting an option must not colour the ones behind it)."""
+    yield
+    if "renderer" in request.fixturenames:
+        r = request.getfixturevalue("renderer")
+        from ray_tracing_in_one_weekend_amd import _ffi
+        for opt in _ffi.OPT_NAMES.values():
+            r.set_option(opt, 0)

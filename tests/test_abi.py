@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef RT_PROFILE_LANES.*?#endif", "", src, flags=re.S)  # diagnostic builds only, absent from the product library
     names = re.findall(r"^\s*(?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\*?\s+\*?\s*((?:rt|rth)_[a-z0-9_]+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
@@ -23,7 +24,11 @@ def test_gpu_library_exports_every_declared_symbol(rt):
     assert set(names) == set(rt._ffi.GPU_SYMBOLS), (names, rt._ffi.GPU_SYMBOLS)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.rt_abi_version() == 7 == rt._ffi.EXPECTED_ABI
+    # ... and nothing else with C linkage: exported == declared, debug entry points included
+    nm = subprocess.run(["nm", "-D", "--defined-only", rt._ffi.GPU_LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = sorted(ln.split()[-1] for ln in nm.splitlines() if re.search(r" T rt_[a-z0-9_]+$", ln))
+    assert exported == names, set(exported) ^ set(names)
+    assert lib.rt_abi_version() == 8 == rt._ffi.EXPECTED_ABI
     assert len(lib.rt_build_id()) in (7, 16)  # "unknown" or 16 hex digits
 
 
@@ -69,6 +74,14 @@ def test_context_creation_fails_loudly_without_a_gpu(rt):
         pytest.skip("a GPU is present")
     with pytest.raises(rt.RtError, match="rt_ctx_create"):
         rt.Renderer(0)
+
+
+def test_the_libraries_read_no_environment_variable():
+    """Configuration goes through the C-ABI (rt_debug_set_option: per context), never through the process environment."""
+    for sub in ("csrc", "host"):
+        d = os.path.join(ROOT, "ray_tracing_in_one_weekend_amd", sub)
+        for fn in os.listdir(d):
+            assert "getenv" not in open(os.path.join(d, fn), errors="ignore").read(), fn
 
 
 def test_product_package_never_imports_the_oracle():

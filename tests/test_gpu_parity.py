@@ -66,6 +66,147 @@ def _check_production_kernels(rt, orc, renderer, scene, o, d, depth):
     assert not p["radiance"][live].any()  # emitted = 0 for everything that scatters (material.rs:12-14)
 
 
+def _false_positive_of_fp32_sphere_hit(o, d, c, r, sph):
+    """True when the ray misses sphere `sph` in exact (float64) geometry: a root that fp32 Sphere::hit (hitable.rs:79-83)
+    reports only because |oc|^2 - r^2 cancelled.  A box test — the reference's own AABB::hit included — may cull such a hit."""
+    oc = o.astype(np.float64) - c[sph]
+    dd = d.astype(np.float64)
+    dist2 = oc @ oc - (oc @ dd) ** 2 / (dd @ dd)
+    return dist2 > (r[sph] * (1 + 1e-6)) ** 2
+
+
+@pytest.mark.parametrize("name", ["sphere_scene", "pbr_sweep_scene"])
+def test_grid_walk_equals_tree_and_list_walk(rt, orc, renderer, name):
+    """Sphere-only scenes answer depth >= 1 by a 3D-DDA walk over a uniform grid in LDS (csrc/rt_grid.h).  Through the
+    production kernels, on adversarial rays (axis-parallel, origins inside / on spheres, grazing, 1e6 away, near-axis) and on
+    the rays of the scene: grid == list walk == oracle bit for bit; grid == tree except where the list walk's hit is a
+    false positive of fp32 Sphere::hit that a box test culls.  Every cell size gives the same records."""
+    scene = rt.Scene.build(name, 16 / 9)
+    a = scene.arrays()
+    rng = np.random.default_rng(11)
+    c = np.stack([a["sph_cx"], a["sph_cy"], a["sph_cz"]], 1).astype(np.float64)
+    r = np.abs(a["sph_r"].astype(np.float64))
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float32)
+    o_list, d_list = [], []
+    for k in range(6000):
+        s_ = rng.integers(0, len(r))
+        ax = axes[rng.integers(0, 6)]
+        kind = k % 6
+        if kind == 0:    # axis-aligned ray through a sphere centre from outside
+            o_list.append(c[s_] - ax * (r[s_] * 3 + 1)); d_list.append(ax)
+        elif kind == 1:  # origin at the centre of a sphere
+            o_list.append(c[s_]); d_list.append(ax)
+        elif kind == 2:  # grazing: offset by exactly r perpendicular to the direction
+            perp = axes[(np.argmax(np.abs(ax)) * 2 + 2) % 6]
+            o_list.append(c[s_] + perp * r[s_] - ax * 5); d_list.append(ax)
+        elif kind == 3:  # very far origin: beyond the grid's coordinate limit, every sphere is tested
+            o_list.append(c[s_] - ax * 1e6); d_list.append(ax)
+        elif kind == 4:  # random direction from a point on the sphere surface
+            v = rng.normal(size=3); v /= np.linalg.norm(v)
+            o_list.append(c[s_] + v * r[s_]); w = rng.normal(size=3).astype(np.float32)
+            d_list.append(w * (np.float32(1) / np.sqrt(np.float32(w[0] * w[0] + w[1] * w[1]) + np.float32(w[2] * w[2]))))
+        else:            # a long, nearly axis-parallel ray skimming the layer of small spheres
+            w = ax.astype(np.float32) + rng.normal(size=3).astype(np.float32) * np.float32(10.0 ** -rng.integers(2, 9))
+            o_list.append(c[s_] - ax * 30 + rng.normal(size=3) * 0.1); d_list.append(w)
+    o = np.asarray(o_list, np.float32)
+    d = np.asarray(d_list, np.float32)
+    o2, d2, _ = rays_on_scene(20000, 5)
+    o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+    keys = path_keys(0, np.arange(len(o)), np.zeros(len(o), dtype=np.uint64))
+    prod = rt._ffi.FLAG_PRODUCTION_KERNELS
+    renderer.upload(scene)
+    info = renderer.scene_info()
+    assert info["grid"] and info["grid_lds_bytes"] <= 80 * 1024 and info["grid_refs"] > 0, info
+    g = renderer.debug_bounce(o, d, keys, depth=3, flags=prod)
+    renderer.set_option("grid", 1)
+    t = renderer.debug_bounce(o, d, keys, depth=3, flags=prod)
+    renderer.set_option("grid", 0)
+    b = renderer.debug_bounce(o, d, keys, depth=3, flags=rt._ffi.FLAG_BRUTE_FORCE | prod)
+    ref = orc.debug_bounce(scene.flat_ptr, o, d, keys, depth=3, accel=orc.ACCEL_LIST)
+    assert np.array_equal(b["hit"], ref["hit"]) and np.array_equal(b["t"].view(np.uint32), ref["t"].view(np.uint32))
+    for label, x in (("grid", g), ("tree", t)):
+        same = (x["hit"] == b["hit"]) & (x["t"].view(np.uint32) == b["t"].view(np.uint32))
+        for i in np.flatnonzero(~same):  # a culled hit must be a miss in exact geometry
+            assert b["hit"][i] >= 0 and _false_positive_of_fp32_sphere_hit(o[i], d[i], c, r, b["hit"][i]), (label, i)
+            # ... and what the search returns instead is what the list walk returns once that sphere is gone: another
+            # accepted root behind it, or a miss
+            assert x["hit"][i] != b["hit"][i] and (x["hit"][i] < 0 or x["t"][i] >= b["t"][i]), (label, i)
+        far = np.arange(len(o)) < 6000
+        assert same[~far].mean() > 0.9999, label
+    kind3 = (np.arange(len(o)) % 6 == 3) & (np.arange(len(o)) < 6000)
+    assert np.array_equal(g["hit"][kind3], b["hit"][kind3])  # far origins: the grid kernel tests every sphere, like the list walk
+    assert (g["hit"] >= 0).mean() > 0.5
+    # every cell size gives the same records; the cells are what was asked for
+    n_other = 0
+    for per_mille in (700, 1000, 2000, 3000):
+        renderer.set_option("grid_cell", per_mille)
+        renderer.upload(scene)
+        info2 = renderer.scene_info()
+        if not info2["grid"]:  # (a cell size the scene does not admit: too many references per cell, csrc/rt_grid.h)
+            continue
+        assert info2["grid_cells"] != info["grid_cells"], (per_mille, info2)
+        n_other += 1
+        g2 = renderer.debug_bounce(o, d, keys, depth=3, flags=prod)
+        near = ~kind3
+        differ = (g2["hit"] != g["hit"]) | (g2["t"].view(np.uint32) != g["t"].view(np.uint32))
+        for i in np.flatnonzero(differ & near):  # only fp32 false positives may depend on which cells a ray visits
+            w = g2 if g2["hit"][i] >= 0 and (g["hit"][i] < 0 or g2["t"][i] < g["t"][i]) else g
+            assert _false_positive_of_fp32_sphere_hit(o[i], d[i], c, r, w["hit"][i]), (per_mille, i)
+        assert differ.mean() < 1e-4
+    assert n_other >= 2
+    renderer.set_option("grid_cell", 0)
+    renderer.upload(scene)
+    # whole frames (queues, refills, deep bounces): grid == tree == list walk, bit for bit, ray counts included
+    p = rt.make_params(240, 135, 6, max_depth=50, seed=9)
+    f_grid, _, s_grid = renderer.render(scene.camera, p)
+    renderer.set_option("grid", 1)
+    f_tree, _, s_tree = renderer.render(scene.camera, p)
+    renderer.set_option("grid", 0)
+    p.flags = rt._ffi.FLAG_BRUTE_FORCE
+    f_list, _, s_list = renderer.render(scene.camera, p)
+    assert np.array_equal(f_grid.view(np.uint32), f_list.view(np.uint32)) and np.array_equal(f_tree.view(np.uint32), f_list.view(np.uint32))
+    assert list(s_grid.rays_per_depth) == list(s_list.rays_per_depth) == list(s_tree.rays_per_depth)
+
+
+def test_grid_is_built_only_where_it_suits(rt, renderer):
+    """rt_scene_upload builds the grid for sphere-only scenes of similar spheres and leaves the others to the tree: too few
+    spheres, general scenes, spheres of wildly different sizes or coordinates the fp32 walk could not resolve."""
+    f = rt._ffi
+    for name, want in (("sphere_scene", True), ("pbr_sweep_scene", True), ("test_sphere", False), ("earth_env_scene", False),
+                       ("cornell_box", False), ("final_scene", False), ("simple_light_scene", False)):
+        renderer.upload(rt.Scene.build(name, 16 / 9))
+        assert bool(renderer.scene_info()["grid"]) == want, name
+    rng = np.random.default_rng(2)
+
+    def cloud(centres, radii):
+        s = rt.Scene.new()
+        m = s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.6, 0.6, 0.6)))
+        for c_, r_ in zip(centres, radii):
+            s.sphere(tuple(float(x) for x in c_), float(r_), m, "s")
+        s.set_camera((0, 2, 30), (0, 0, 0), (0, 1, 0), 40, 1.5)
+        s.finish()
+        return s
+    # 300 equal spheres far from the origin: cells of 0.2 at coordinates of 1e6 are below what fp32 resolves -> tree
+    far = cloud(rng.uniform(-5, 5, (300, 3)) + 1e6, np.full(300, 0.1))
+    renderer.upload(far)
+    assert not renderer.scene_info()["grid"]
+    # radii over four decades: more than four "large" spheres at every cell size tried, or too many references -> tree
+    renderer.upload(cloud(rng.uniform(-5, 5, (300, 3)), 10.0 ** rng.uniform(-3, 1, 300)))
+    assert not renderer.scene_info()["grid"]
+    # a plain cloud gets one, negative radii (hollow glass, as in the book) and zero radii included, and renders like the tree
+    radii = np.full(400, 0.25)
+    radii[::7] = -0.25
+    radii[3::50] = 0.0
+    s = cloud(rng.uniform(-6, 6, (400, 3)) * np.array([1, 0.2, 1]), radii)
+    renderer.upload(s)
+    assert renderer.scene_info()["grid"]
+    p = rt.make_params(160, 120, 4, max_depth=10)
+    a_, _, sa = renderer.render(s.camera, p)
+    renderer.set_option("grid", 1)
+    b_, _, sb = renderer.render(s.camera, p)
+    assert np.array_equal(a_.view(np.uint32), b_.view(np.uint32)) and list(sa.rays_per_depth) == list(sb.rays_per_depth)
+
+
 def test_bounce_sphere_scene_all_depth_blocks(rt, orc, renderer):
     scene = rt.Scene.build("sphere_scene", 16 / 9)
     for depth in (0, 1, 7, 50):
@@ -230,9 +371,9 @@ def test_many_samples_and_uneven_slices(rt, orc, renderer, name, nx, ny):
         assert np.array_equal(im2.view(np.uint32), img.view(np.uint32)), s
 
 
-def test_texel_pool_rgba8_and_float_fallback(rt, orc, renderer, monkeypatch):
+def test_texel_pool_rgba8_and_float_fallback(rt, orc, renderer):
     """An image whose texels are all k/255 (any decoded 8-bit file, texture.rs:176-177) is kept as RGBA8 on the device and
-    (float)k / 255 is taken at the lookup: the same frame, bit for bit, as with the float4 pool (RTOW_FLOAT_TEXELS=1).
+    (float)k / 255 is taken at the lookup: the same frame, bit for bit, as with the float4 pool (RT_OPT_TEXEL_POOL = 1).
     An image with other values takes the float4 pool.  Both against the oracle."""
     rng = np.random.default_rng(7)
     for name, pixels in (("test/eight_bit.img", (rng.integers(0, 256, (32, 64, 3)).astype(np.float32) / np.float32(255.0))),
@@ -252,10 +393,10 @@ def test_texel_pool_rgba8_and_float_fallback(rt, orc, renderer, monkeypatch):
         ref, _, so = _oracle(orc, s, p)
         assert st.n_rays == so.n_rays and st.n_texture_fetches == so.n_texture_fetches > 0
         _compare_frames(orc, s, p, img_a, ref, name, rt, renderer)
-        monkeypatch.setenv("RTOW_FLOAT_TEXELS", "1")
+        renderer.set_option("texel_pool", 1)
         renderer.upload(s)
         img_b, _, _ = renderer.render(s.camera, p)
-        monkeypatch.delenv("RTOW_FLOAT_TEXELS")
+        renderer.set_option("texel_pool", 0)
         assert np.array_equal(img_a.view(np.uint32), img_b.view(np.uint32)), name
 
 
@@ -277,7 +418,7 @@ def test_tall_narrow_frame_up_to_the_row_limit(rt, orc, renderer):
     assert part.shape[0] == 1 << 20
 
 
-def test_tile_order_of_path_slots_does_not_change_images(rt, renderer, monkeypatch):
+def test_tile_order_of_path_slots_does_not_change_images(rt, renderer):
     """Path slots enumerate the pixels of a shard in 8 x 8 tiles (one wave of depth 0 = one tile) when nx is a multiple of 8 —
     the last rows % 8 rows and other widths in rows (rt_kernels.h GenParams::tiles_per_row).  Keys, candidate lists, the sample sum and
     the output image are functions of the pixel, not of its slot: frames, RGB8 and ray counts are the same bit for bit either
@@ -287,11 +428,11 @@ def test_tile_order_of_path_slots_does_not_change_images(rt, renderer, monkeypat
         renderer.upload(scene)
         for kw in ({}, {"spp_slice": 3}, {"shard_band": 8, "shard_count": 3, "shard_id": 1}, {"shard_band": 4, "shard_count": 2, "shard_id": 0}):
             p = rt.make_params(nx, ny, 6, max_depth=12, seed=3, **kw)
-            monkeypatch.setenv("RTOW_ROW_MAJOR", "1")
+            renderer.set_option("pixel_order", 1)
             rows, rows8, sr = renderer.render(scene.camera, p, want_rgb8=True)
-            monkeypatch.setenv("RTOW_ROW_MAJOR", "0")
+            renderer.set_option("pixel_order", 2)
             tiles, tiles8, st = renderer.render(scene.camera, p, want_rgb8=True)
-            monkeypatch.delenv("RTOW_ROW_MAJOR")
+            renderer.set_option("pixel_order", 0)
             assert np.array_equal(rows.view(np.uint32), tiles.view(np.uint32)) and np.array_equal(rows8, tiles8), (name, kw)
             assert sr.n_rays == st.n_rays and list(sr.rays_per_depth) == list(st.rays_per_depth)
 
@@ -1014,18 +1155,20 @@ def test_constant_medium_and_cornell_box(rt, orc, renderer):
 
 
 @pytest.mark.gpu
-def test_hbm_resident_bvh_matches_lds(rt, renderer, monkeypatch):
+def test_hbm_resident_bvh_matches_lds(rt, renderer):
     """Scenes whose tree exceeds LDS traverse it out of HBM/L2; forcing that path on sphere_scene must give the
     LDS path's frame bit for bit (same tree, same traversal order, same tie rule)."""
     scene = rt.Scene.build("sphere_scene", 16 / 9)
     p = rt.make_params(240, 135, 8, max_depth=50)
     renderer.upload(scene)
     a, _, sa = renderer.render(scene.camera, p)
-    monkeypatch.setenv("RTOW_BVH_HBM", "1")
+    renderer.set_option("tree_placement", 1)
     renderer.upload(scene)
+    assert not renderer.scene_info()["tree_in_lds"] and not renderer.scene_info()["grid"]
     b, _, sb = renderer.render(scene.camera, p)
-    monkeypatch.delenv("RTOW_BVH_HBM")
+    renderer.set_option("tree_placement", 0)
     renderer.upload(scene)
+    assert renderer.scene_info()["tree_in_lds"]
     assert int(sa.n_rays) == int(sb.n_rays) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
@@ -1095,7 +1238,7 @@ def test_progressive_preview_and_driver(rt, renderer, tmp_path):
 
 
 @pytest.mark.gpu
-def test_primary_candidate_lists_do_not_change_images(rt, renderer, monkeypatch):
+def test_primary_candidate_lists_do_not_change_images(rt, renderer):
     """k_primary_lists: depth 0 tests the entries listed for the pixel instead of walking the tree.  The lists are
     conservative and the closest-hit rule is order-independent, so frames are bit-identical with and without them —
     on every mirrored scene, for a sharded frame, and with the eye inside a primitive's bounding sphere."""
@@ -1106,9 +1249,9 @@ def test_primary_candidate_lists_do_not_change_images(rt, renderer, monkeypatch)
         renderer.upload(scene)
         p = rt.make_params(nx, ny, 8, max_depth=12)
         a, _, sa = renderer.render(scene.camera, p)
-        monkeypatch.setenv("RTOW_NO_PRIMARY_LISTS", "1")
+        renderer.set_option("primary_lists", 1)
         b, _, sb = renderer.render(scene.camera, p)
-        monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS")
+        renderer.set_option("primary_lists", 0)
         assert int(sa.n_rays) == int(sb.n_rays), name
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
     # sharded rows use local pixel indices for the lists
@@ -1132,14 +1275,14 @@ def test_primary_candidate_lists_do_not_change_images(rt, renderer, monkeypatch)
     renderer.upload(s)
     p = rt.make_params(150, 100, 8, max_depth=8)
     a, _, _ = renderer.render(s.camera, p)
-    monkeypatch.setenv("RTOW_NO_PRIMARY_LISTS", "1")
+    renderer.set_option("primary_lists", 1)
     b, _, _ = renderer.render(s.camera, p)
-    monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS")
+    renderer.set_option("primary_lists", 0)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.std() > 0.01
 
 
 @pytest.mark.gpu
-def test_config2_full_size_three_searches_agree(rt, renderer, monkeypatch):
+def test_config2_full_size_three_searches_agree(rt, renderer):
     """BASELINE config 2 at full size (1920x1080, 256 spp, depth 50): candidate lists, tree and list walk give the same
     frame bit for bit.  Ray counts may differ by the handful of grazing rays for which fp32 Sphere::hit reports a hit
     outside the padded box (2 of 1.35e9 on this frame) — lists == list walk exactly."""
@@ -1147,9 +1290,9 @@ def test_config2_full_size_three_searches_agree(rt, renderer, monkeypatch):
     renderer.upload(scene)
     p = rt.make_params(1920, 1080, 256, max_depth=50)
     a, _, sa = renderer.render(scene.camera, p)
-    monkeypatch.setenv("RTOW_NO_PRIMARY_LISTS", "1")
+    renderer.set_option("primary_lists", 1)
     b, _, sb = renderer.render(scene.camera, p)
-    monkeypatch.delenv("RTOW_NO_PRIMARY_LISTS")
+    renderer.set_option("primary_lists", 0)
     c, _, sc = renderer.render(scene.camera, rt.make_params(1920, 1080, 256, max_depth=50, flags=rt._ffi.FLAG_BRUTE_FORCE))
     assert sa.n_paths == 1920 * 1080 * 256 and sa.n_slices in (1, 2)  # one slice when HBM has 62 GB to give
     assert np.array_equal(a.view(np.uint32), c.view(np.uint32)) and np.array_equal(b.view(np.uint32), c.view(np.uint32))
