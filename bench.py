@@ -219,12 +219,83 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def trace_roofline(trace_bytes, trace_s):
+    achieved = trace_bytes / max(trace_s, 1e-12) / 1e9
+    return round(achieved, 2), round(achieved / HBM_PEAK_GBPS, 5)
+
+
+def build_record(*, config_id, cfg, nx, ny, spp, spp_total, scaling, max_depth, band, world, backend, steps, warmup, elapsed_max,
+                 rays_total, gather_ms, per_rank, rank0, build_id, rendered=True):
+    """The JSON line of rank 0 from the aggregated measurements (pure: the CPU test of the multi-rank launch path builds the
+    same line from a rehearsal's numbers).  per_rank: [(trace_seconds, trace_bytes_algorithmic)] of every rank over the timed
+    steps; rank0: dict of rank 0's last RtStats fields + launch totals (None when nothing was rendered)."""
+    gather_name = "RCCL all_gather over xGMI" if backend == "nccl" else f"{backend} all_gather through host memory (rehearsal)"
+    per_gpu = f"{spp} spp per GPU ({spp_total} spp total)" if scaling == "weak" else f"{spp_total} spp"
+    workload = (f"config {config_id}: {cfg['what']} {nx}x{ny}, {per_gpu}, max_depth {max_depth}, "
+                f"seed 95, counter RNG; rows sharded in bands of {band} over {world} GPU(s)"
+                + (f", {gather_name} of the f32 framebuffer per step" if world > 1 else ""))
+    r0 = rank0 or {}
+    trace_s, trace_bytes = per_rank[0] if per_rank else (0.0, 0)
+    achieved, frac = trace_roofline(trace_bytes, trace_s) if rendered else (None, None)
+    launches = r0.get("launches", 0)
+    traffic, traffic_src = pmc_traffic(workload, build_id) if rendered else (None, None)
+    out = {
+        # BASELINE.json's metric is quoted on config 2; the other configs carry their own frame in the label
+        "metric": f"Mray/s (primary+secondary) at {nx}x{ny}/{spp_total}spp",
+        "value": round(rays_total / max(elapsed_max, 1e-12) / 1e6, 3) if rendered else None,
+        "unit": "Mray/s",
+        "n_gpus": world,
+        "rccl_ranks": world if (backend == "nccl" and world > 1) else 0,  # ranks of the RCCL communicator the gather ran on
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(elapsed_max / max(steps, 1) * 1e3, 3) if rendered else None,
+        "gather_ms": gather_ms,  # all_gather + de-interleave per step, HIP events on the launch stream, max over ranks (null on 1 GPU)
+        "higher_is_better": True,
+        "scaling": scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": workload,
+                   "paths_per_step": int(r0.get("n_paths", 0)) * world, "rays_per_step_rank0": int(r0.get("n_rays", 0)),
+                   "rays_per_path": round(r0.get("n_rays", 0) / max(r0.get("n_paths", 0), 1), 4),
+                   "texture_fetches_per_step_rank0": int(r0.get("n_texture_fetches", 0)),
+                   "spp_slices": int(r0.get("n_slices", 0))},
+        "roofline": {"kernel": "trace step = closest hit (k_intersect / k_intersect_grid) + k_shade (the survey's k_trace_shade, split)",
+                     "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac,
+                     # every rank's own trace step (rank order): a curve over N carries its HBM fraction per GPU
+                     "per_rank": [dict(zip(("achieved", "frac"), trace_roofline(b, t))) for t, b in per_rank] if rendered else [],
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "valu": pmc_valu(workload, build_id) if rendered else None,
+                     "bytes_per_launch": round(trace_bytes / max(launches, 1), 1),
+                     "avg_launch_us": round(trace_s / max(launches, 1) * 1e6, 3),
+                     "launches": launches,
+                     "note": "per launch = one kernel of one depth over all shards (2 per depth; each runs as two concurrent half-grid dispatches on two "
+                             "streams, so rocprof lists twice as many dispatches of about this duration); algorithmic bytes = "
+                             "48 B/ray read + 48 B/surviving ray written + 12 B/path radiance + 12 B/ImageTex fetch (SURVEY.md 8(d): "
+                             "96 B/ray + 24 B/path + 12 B/fetch over gen+trace+resolve); time = HIP events around the trace launches "
+                             "of every slice on the launch stream; traffic = PMC FETCH_SIZE*2 + WRITE_SIZE of both kernels per launch "
+                             "(x2 calibrated for streams AND gathers: profiles/round3/fetch_calibration.json).  The algorithmic figure "
+                             "follows the SURVEY 8(d) CONVENTION of a 48 B ray record; the records this layout moves are 40 B + an 8 B "
+                             "hit record between the kernels, i.e. the same 48 B per ray read and 40 B per survivor written"},
+        "library_build_id": build_id,
+    }
+    if rendered:
+        out["whole_path"] = {"bytes_algorithmic_per_step": int(r0["bytes_algorithmic"]),
+                             "device_seconds_per_step": round(r0["seconds_device"], 6),
+                             "hbm_frac": round(r0["bytes_algorithmic"] / max(r0["seconds_device"], 1e-12) / 1e9 / HBM_PEAK_GBPS, 5)}
+    else:
+        out["rendered"] = False
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(CONFIGS),
+                    help="BASELINE.json config; default: 2 on one GPU, 3 (the 8-GPU frame, strong scaling) with --gpus N > 1")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None)
     ap.add_argument("--nx", type=int, default=0)
     ap.add_argument("--ny", type=int, default=0)
@@ -234,8 +305,8 @@ def main():
     ap.add_argument("--band", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
-                    help="only the warm-up and the timed steps: no CPU baseline, no host-inclusive leg, no in-library check (the runs "
-                         "that rocprofv3 counts: scripts/collect_traffic.py, collect_valu.py, the kernel statistics)")
+                    help="only the warm-up and the timed steps: no CPU baseline, no host-inclusive leg, no in-library check, no second "
+                         "workload (the runs that rocprofv3 counts: scripts/collect_traffic.py, collect_valu.py, the kernel statistics)")
     ap.add_argument("--in-library", action="store_true",
                     help="after the timed region, rank 0 also renders through rt_multi_render (one process, all --gpus devices, the RCCL "
                          "gather inside the library) and reports bit-identity with rt_render; always on when --gpus > 1")
@@ -271,7 +342,16 @@ def main():
     # RTOW_DIST_BACKEND=gloo: rehearsal of the multi-process path on a box with fewer GPUs than ranks
     # (ranks share devices, the gather goes through host memory); the real run is nccl == RCCL over xGMI
     backend = os.environ.get("RTOW_DIST_BACKEND", "nccl")
-    gather_name = "RCCL all_gather over xGMI" if backend == "nccl" else f"{backend} all_gather through host memory (rehearsal)"
+    # the workload: config 2 on one GPU (BASELINE.json's metric), config 3 — the frame north_star names for the 8 GPUs of a node,
+    # split N ways — when there are several and nothing else was asked for
+    config_id = args.config or (2 if world == 1 else 3)
+    cfg = CONFIGS[config_id]
+    nx, ny = args.nx or cfg["nx"], args.ny or cfg["ny"]
+    spp = args.spp or cfg["spp"]
+    scaling = args.scaling or cfg["scaling"]
+    spp_total = spp * world if scaling == "weak" else spp
+    common = dict(config_id=config_id, cfg=cfg, nx=nx, ny=ny, spp=spp, spp_total=spp_total, scaling=scaling, max_depth=args.max_depth,
+                  band=args.band, world=world, steps=args.steps, warmup=args.warmup)
 
     if args.launcher_check:
         from ray_tracing_in_one_weekend_amd import shard
@@ -288,19 +368,24 @@ def main():
             else:
                 dist.init_process_group(backend="gloo")
             assert dist.get_world_size() == n_req
-        ny, nx = 64, 16
-        rows = shard.shard_rows(ny, args.band, world, rank)
-        local = torch.zeros((len(rows), nx, 3), dtype=torch.float32, device=dev)
+        cny, cnx = 64, 16
+        rows = shard.shard_rows(cny, args.band, world, rank)
+        local = torch.zeros((len(rows), cnx, 3), dtype=torch.float32, device=dev)
         local[:, :, 0] = torch.as_tensor(rows, dtype=torch.float32, device=dev)[:, None]  # every pixel carries its image row
-        full = shard.gather_framebuffer(local, ny, args.band) if world > 1 else local
-        ok = bool((full[:, 0, 0].cpu() == torch.arange(ny, dtype=torch.float32)).all())
+        t0 = time.perf_counter()
+        full = shard.gather_framebuffer(local, cny, args.band) if world > 1 else local
+        gather_ms = round((time.perf_counter() - t0) * 1e3, 3) if world > 1 else None
+        ok = bool((full[:, 0, 0].cpu() == torch.arange(cny, dtype=torch.float32)).all())
         if world > 1:
             dist.barrier()
         if rank == 0:
             ran = "nccl" if (on_rccl and world > 1) else "gloo"
-            emit({"launcher_check": ok, "n_gpus": world, "rccl_ranks": world if ran == "nccl" else 0,
-                  "backend": ran, "gather": "RCCL all_gather over xGMI" if ran == "nccl" else
-                  "gloo all_gather through host memory (rehearsal)"})
+            # the line a rendering run of these arguments would print, with nothing rendered: same keys, the launch path's own numbers
+            rec = build_record(**common, backend=ran, elapsed_max=0.0, rays_total=0.0, gather_ms=gather_ms,
+                               per_rank=[(0.0, 0)] * world, rank0=None, build_id=None, rendered=False)
+            rec.update({"launcher_check": ok, "rccl_ranks": world if ran == "nccl" else 0, "backend": ran,
+                        "gather": "RCCL all_gather over xGMI" if ran == "nccl" else "gloo all_gather through host memory (rehearsal)"})
+            emit(rec)
         if world > 1:
             dist.destroy_process_group()
         sys.exit(0 if ok else 1)
@@ -319,36 +404,14 @@ def main():
     import ray_tracing_in_one_weekend_amd as rt
     from ray_tracing_in_one_weekend_amd import shard
 
-    cfg = CONFIGS[args.config]
-    nx, ny = args.nx or cfg["nx"], args.ny or cfg["ny"]
-    spp = args.spp or cfg["spp"]
-    scaling = args.scaling or cfg["scaling"]
     rt.register_default_images()
-    scene = rt.Scene.build(cfg["scene"], nx / ny)
     renderer = rt.Renderer(device_index)  # raises if librtow_mi355x.so is missing
-    renderer.upload(scene)
-    spp_total = spp * world if scaling == "weak" else spp
-    params = rt.make_params(nx, ny, spp_total, max_depth=args.max_depth, seed=95, shard_band=args.band,
-                            shard_count=world, shard_id=rank, spp_slice=args.spp_slice)
-    rows = renderer.shard_rows(params)
     # a dedicated non-default stream: the library's launches, its HIP events and the RCCL gather are
     # all ordered on it (stream handle 0 would make the library fall back to its own stream); the band
     # buffer is allocated on that stream too
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
-    local = torch.zeros((rows, nx, 3), dtype=torch.float32, device="cuda")
     stream = tstream.cuda_stream
-
-    def step(want_stats):
-        st = renderer.render_device(scene.camera, params, local.data_ptr(), stream=stream, want_stats=want_stats)
-        if world > 1 and backend == "nccl":
-            full = shard.gather_framebuffer(local, ny, args.band)  # RCCL all_gather + de-interleave
-        elif world > 1:
-            torch.cuda.current_stream().synchronize()
-            full = shard.gather_framebuffer(local.cpu(), ny, args.band)
-        else:
-            full = local
-        return st, full
 
     def fence():
         torch.cuda.synchronize()
@@ -364,26 +427,80 @@ def main():
         dist.all_reduce(c, op=op)
         return c
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    stats = []
-    for _ in range(args.steps):
-        st, full = step(True)  # reading the counters synchronises; the counters are part of the metric
-        stats.append(st)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def run_workload(scene, w_nx, w_ny, w_spp_total, steps, warmup):
+        """warm-up, then exactly `steps` timed steps between fences; returns the aggregated measurements of all ranks"""
+        params = rt.make_params(w_nx, w_ny, w_spp_total, max_depth=args.max_depth, seed=95, shard_band=args.band,
+                                shard_count=world, shard_id=rank, spp_slice=args.spp_slice)
+        rows = renderer.shard_rows(params)
+        local = torch.zeros((rows, w_nx, 3), dtype=torch.float32, device="cuda")
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if world > 1 else []
 
-    rays_local = sum(s.n_rays for s in stats)
-    t = torch.tensor([elapsed, float(rays_local), sum(s.seconds_trace for s in stats),
-                      float(sum(s.bytes_trace_algorithmic for s in stats))], dtype=torch.float64, device="cuda")
-    if world > 1:
-        tmax = reduce_(t.clone(), dist.ReduceOp.MAX)
-        tsum = reduce_(t.clone(), dist.ReduceOp.SUM)
-        elapsed_max, rays_total = tmax[0].item(), tsum[1].item()
-    else:
-        elapsed_max, rays_total = elapsed, float(rays_local)
+        def step(want_stats, k=None):
+            st = renderer.render_device(scene.camera, params, local.data_ptr(), stream=stream, want_stats=want_stats)
+            if world > 1 and backend == "nccl":
+                if k is not None:
+                    ev[k][0].record()
+                full = shard.gather_framebuffer(local, w_ny, args.band)  # RCCL all_gather + de-interleave
+                if k is not None:
+                    ev[k][1].record()
+            elif world > 1:
+                torch.cuda.current_stream().synchronize()
+                t0 = time.perf_counter()
+                full = shard.gather_framebuffer(local.cpu(), w_ny, args.band)
+                if k is not None:
+                    ev[k] = (time.perf_counter() - t0) * 1e3
+            else:
+                full = local
+            return st, full
+
+        for _ in range(warmup):
+            step(False)
+        fence()
+        t0 = time.perf_counter()
+        stats = []
+        for k in range(steps):
+            st, _ = step(True, k)  # reading the counters synchronises; the counters are part of the metric
+            stats.append(st)
+        fence()
+        elapsed = time.perf_counter() - t0
+        gather_ms_local = 0.0
+        if world > 1:
+            gather_ms_local = sum((e if isinstance(e, float) else e[0].elapsed_time(e[1])) for e in ev) / max(steps, 1)
+        trace_s = sum(s.seconds_trace for s in stats)
+        trace_bytes = float(sum(s.bytes_trace_algorithmic for s in stats))
+        t = torch.tensor([elapsed, float(sum(s.n_rays for s in stats)), gather_ms_local], dtype=torch.float64, device="cuda")
+        per_rank = [(trace_s, trace_bytes)]
+        if world > 1:
+            tmax = reduce_(t.clone(), dist.ReduceOp.MAX)
+            tsum = reduce_(t.clone(), dist.ReduceOp.SUM)
+            elapsed_max, rays_total, gather_ms = tmax[0].item(), tsum[1].item(), round(tmax[2].item(), 3)
+            mine = torch.tensor([trace_s, trace_bytes], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            per_rank = [(float(q[0]), float(q[1])) for q in parts]
+        else:
+            elapsed_max, rays_total, gather_ms = elapsed, t[1].item(), None
+        s0 = stats[-1]
+        rank0 = {"n_paths": s0.n_paths, "n_rays": s0.n_rays, "n_texture_fetches": s0.n_texture_fetches, "n_slices": s0.n_slices,
+                 "bytes_algorithmic": s0.bytes_algorithmic, "seconds_device": s0.seconds_device,
+                 "launches": sum(s.n_trace_launches for s in stats)}
+        del local
+        return dict(elapsed_max=elapsed_max, rays_total=rays_total, gather_ms=gather_ms, per_rank=per_rank, rank0=rank0), params
+
+    scene = rt.Scene.build(cfg["scene"], nx / ny)
+    renderer.upload(scene)
+    meas, params = run_workload(scene, nx, ny, spp_total, args.steps, args.warmup)
+
+    # With several GPUs and the default workload, the one-GPU headline frame rides along: config 2, weak scaling (every rank
+    # 1080 / N rows x 256 N samples), two timed steps — the curve the round-3 lines were on
+    also = None
+    if world > 1 and not args.config and not args.timed_only:
+        c2 = CONFIGS[2]
+        scene2 = rt.Scene.build(c2["scene"], c2["nx"] / c2["ny"])
+        renderer.upload(scene2)
+        m2, _ = run_workload(scene2, c2["nx"], c2["ny"], c2["spp"] * world, 2, 1)
+        also = (c2, m2)
+        renderer.upload(scene)
 
     if world > 1:  # every collective of the measurement is behind us: the other ranks leave and free their GPUs
         dist.barrier()
@@ -392,65 +509,23 @@ def main():
     if rank == 0 and (args.in_library or world > 1) and not args.timed_only:
         in_library = in_library_check(rt, scene, renderer, (nx, ny, spp_total, args.max_depth), world)
     if rank == 0:
-        s0 = stats[-1]
-        trace_s = sum(s.seconds_trace for s in stats)
-        trace_bytes = sum(s.bytes_trace_algorithmic for s in stats)
-        launches = sum(s.n_trace_launches for s in stats)
-        achieved = trace_bytes / max(trace_s, 1e-12) / 1e9
-        per_gpu = f"{spp} spp per GPU ({spp_total} spp total)" if scaling == "weak" else f"{spp_total} spp"
-        workload = (f"config {args.config}: {cfg['what']} {nx}x{ny}, {per_gpu}, max_depth {args.max_depth}, "
-                    f"seed 95, counter RNG; rows sharded in bands of {args.band} over {world} GPU(s)"
-                    + (f", {gather_name} of the f32 framebuffer per step" if world > 1 else ""))
         build_id = renderer.build_id
-        traffic, traffic_src = pmc_traffic(workload, build_id)
-        out = {
-            # BASELINE.json's metric is quoted on config 2; the other configs carry their own frame in the label
-            "metric": f"Mray/s (primary+secondary) at {nx}x{ny}/{spp_total}spp",
-            "value": round(rays_total / elapsed_max / 1e6, 3),
-            "unit": "Mray/s",
-            "n_gpus": world,
-            "rccl_ranks": world if (backend == "nccl" and world > 1) else 0,  # ranks of the RCCL communicator the gather ran on
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / max(args.steps, 1) * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": scaling,
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": workload,
-                       "paths_per_step": int(s0.n_paths) * world, "rays_per_step_rank0": int(s0.n_rays),
-                       "rays_per_path": round(s0.n_rays / max(s0.n_paths, 1), 4),
-                       "texture_fetches_per_step_rank0": int(s0.n_texture_fetches),
-                       "spp_slices": int(s0.n_slices)},
-            "roofline": {"kernel": "trace step = k_intersect + k_shade (the survey's k_trace_shade, split)", "bound": "hbm",
-                         "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "valu": pmc_valu(workload, build_id),
-                         "bytes_per_launch": round(trace_bytes / max(launches, 1), 1),
-                         "avg_launch_us": round(trace_s / max(launches, 1) * 1e6, 3),
-                         "launches": launches,
-                         "note": "per launch = one kernel of one depth over all shards (2 per depth; each runs as two concurrent half-grid dispatches on two "
-                                 "streams, so rocprof lists twice as many dispatches of about this duration); algorithmic bytes = "
-                                 "48 B/ray read + 48 B/surviving ray written + 12 B/path radiance + 12 B/ImageTex fetch (SURVEY.md 8(d): "
-                                 "96 B/ray + 24 B/path + 12 B/fetch over gen+trace+resolve); time = HIP events around the trace launches "
-                                 "of every slice on the launch stream; traffic = PMC FETCH_SIZE*2 + WRITE_SIZE of both kernels per launch "
-                                 "(x2 calibrated for streams AND gathers: profiles/round3/fetch_calibration.json).  The algorithmic figure "
-                                 "follows the SURVEY 8(d) CONVENTION of a 48 B ray record; the records this layout moves are 40 B + an 8 B "
-                                 "hit record between the kernels, i.e. the same 48 B per ray read and 40 B per survivor written"},
-            "library_build_id": build_id,
-            "whole_path": {"bytes_algorithmic_per_step": int(s0.bytes_algorithmic),
-                           "device_seconds_per_step": round(s0.seconds_device, 6),
-                           "hbm_frac": round(s0.bytes_algorithmic / max(s0.seconds_device, 1e-12) / 1e9 / HBM_PEAK_GBPS, 5)},
-        }
+        out = build_record(**common, backend=backend, build_id=build_id, **meas)
+        if also:
+            c2, m2 = also
+            r2 = build_record(config_id=2, cfg=c2, nx=c2["nx"], ny=c2["ny"], spp=c2["spp"], spp_total=c2["spp"] * world, scaling="weak",
+                              max_depth=args.max_depth, band=args.band, world=world, backend=backend, steps=2, warmup=1, build_id=build_id, **m2)
+            out["also"] = {k: r2[k] for k in ("metric", "value", "unit", "ms_per_step", "gather_ms", "scaling", "steps", "warmup")}
+            out["also"]["workload"] = r2["config"]["workload"]
+            out["also"]["roofline"] = {k: r2["roofline"][k] for k in ("achieved", "frac", "per_rank")}
         if world == 1 and not args.timed_only:
-            # the same frame handed to the HOST as the reference's output is (f32 frame + flipped RGB8 through rt_render:
-            # the D2H copies included), never `value`: reported beside it
+            # the same frame handed to the HOST as the reference's output is (f32 frame + flipped RGB8 through rt_render into
+            # page-locked memory of rt_host_alloc: the D2H copies included), never `value`: reported beside it
+            renderer.render(scene.camera, params, want_rgb8=True, pinned=True)  # (the staging buffers' first touch)
             th0 = time.perf_counter()
             host_rays = 0
             for _ in range(max(1, min(args.steps, 3))):
-                _, _, sth = renderer.render(scene.camera, params, want_rgb8=True)
+                _, _, sth = renderer.render(scene.camera, params, want_rgb8=True, pinned=True)
                 host_rays += sth.n_rays
             out["value_host_inclusive"] = round(host_rays / (time.perf_counter() - th0) / 1e6, 3)
         if args.in_library or world > 1:

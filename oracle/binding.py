@@ -28,13 +28,15 @@ def build():
     subprocess.run(["make", "-s", "-C", _DIR, "liboracle.so"], check=True)
 
 
-def load():
+def load(path=None):
+    """dlopen + prototypes.  `path`: another build of the same oracle.cpp (bench.py's -march=native build for the timed
+    CPU baseline) replaces the library behind this module from then on."""
     global _lib
-    if _lib is not None:
+    if _lib is not None and path is None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if path is None and not os.path.exists(LIB_PATH):
         build()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path or LIB_PATH)
     f = C.POINTER(C.c_float)
     lib.orc_render.argtypes = [C.POINTER(RtFlatScene), C.POINTER(RtCamera), C.POINTER(RtParams),
                                C.POINTER(OrcOptions), f, C.POINTER(C.c_uint8), C.POINTER(RtStats)]

@@ -77,6 +77,19 @@ def build_host_library(force=False):
     return out
 
 
+def build_c_host_example(force=False):
+    """gcc -std=c99: examples/host_main.c, a host through nothing but include/*.h (the C stand-in for the reference's main.rs:62-129),
+    linked against the two libraries beside it -> build/host_main"""
+    src = os.path.join(ROOT, "examples", "host_main.c")
+    out = os.path.join(ROOT, "build", "host_main")
+    deps = [src] + [os.path.join(ROOT, "include", f) for f in ("rtow_mi355x.h", "rtow_host.h")]
+    if force or _newer(out, deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        _run(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(ROOT, "include"), "-o", out, src, "-L", PKG_DIR,
+              "-l:librtow_host.so", "-l:librtow_mi355x.so", "-Wl,-rpath,$ORIGIN/../ray_tracing_in_one_weekend_amd"])
+    return out
+
+
 def build_all(force=False):
     """The product libraries only.  The CPU oracle is test infrastructure and builds from its own directory (oracle/build.py)."""
-    return [build_gpu_library(force), build_host_library(force)]
+    return [build_gpu_library(force), build_host_library(force), build_c_host_example(force)]

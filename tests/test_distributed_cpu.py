@@ -86,8 +86,28 @@ def test_bench_launcher_spawns_the_ranks_itself(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["launcher_check"] is True and out["n_gpus"] == 2 and out["backend"] == "gloo"
+    # the line has the shape of the one a rendering 2-GPU run prints: with no --config it is BASELINE's config 3 — the frame
+    # north_star names for the GPUs of a node — under strong scaling, with the gather time and the HBM fraction per rank
+    assert out["config"]["workload"].startswith("config 3:") and "3840x2160" in out["config"]["workload"] and out["scaling"] == "strong"
+    assert out["metric"].endswith("3840x2160/1024spp") and out["rendered"] is False and out["value"] is None
+    assert "frac" in out["roofline"] and "per_rank" in out["roofline"] and out["gather_ms"] > 0
     # a rank count that does not match --gpus is refused, not silently benchmarked as something else
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-check"], env=env2,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bench_record_of_a_two_rank_run():
+    """bench.build_record on the numbers of a 2-rank run: whole-job rays over the slowest rank's time, every rank's own
+    trace-step HBM fraction, the gather time; and a one-GPU default run is config 2."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = bench.CONFIGS[3]
+    r0 = {"n_paths": 10, "n_rays": 25, "n_texture_fetches": 0, "n_slices": 1, "bytes_algorithmic": 4000, "seconds_device": 1e-6, "launches": 4}
+    rec = bench.build_record(config_id=3, cfg=cfg, nx=3840, ny=2160, spp=1024, spp_total=1024, scaling="strong", max_depth=50, band=8, world=2,
+                             backend="nccl", steps=2, warmup=1, elapsed_max=0.5, rays_total=4e9, gather_ms=0.4,
+                             per_rank=[(0.2, 4e11), (0.25, 4e11)], rank0=r0, build_id="0" * 16)
+    assert rec["value"] == 8000.0 and rec["ms_per_step"] == 250.0 and rec["gather_ms"] == 0.4 and rec["rccl_ranks"] == 2
+    assert rec["roofline"]["frac"] == 0.25 and [q["frac"] for q in rec["roofline"]["per_rank"]] == [0.25, 0.2]
+    assert "RCCL all_gather" in rec["config"]["workload"] and rec["config"]["paths_per_step"] == 20

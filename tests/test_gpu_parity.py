@@ -8,18 +8,29 @@ direction and ray counts must match EXACTLY; colours (textures, BRDF weights) to
 images to RMSE <= 2e-4 in display units (gamma-2, clamped [0,1]) against the recursive oracle,
 whose product chain is associated differently from the wavefront's T *= a.
 """
+import os
+
 import numpy as np
 import pytest
 
 from helpers import ctr_draw, display, path_keys, rays_on_scene, rmse_display
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RMSE_TOL = 2e-4
 
 
+def _accel_for(orc, scene):
+    """The oracle's search for a frame comparison: its list walk for scenes with rectangles, wrappers or media (the reference's
+    own BvhNode boxes are unpadded and lose grazing rectangle hits, which the oracle's BVH mode mirrors; the device's padded tree
+    equals the list walk bit for bit), the reference's BVH for spheres."""
+    return orc.ACCEL_LIST if (scene.flat.n_rects or scene.flat.n_media or scene.flat.n_xforms) else orc.ACCEL_BVH
+
+
 def _oracle(orc, scene, params, **kw):
     kw.setdefault("rng_mode", orc.RNG_COUNTER)
+    kw.setdefault("accel", _accel_for(orc, scene))
     return orc.render(scene.flat_ptr, scene.camera, params, orc.options(**kw))
 
 
@@ -468,6 +479,51 @@ def test_render_other_scenes(rt, orc, renderer, name, spp, depth):
     _compare_frames(orc, scene, p, img, ref, name, rt, renderer)
 
 
+def test_the_workload_the_reference_ships(rt, orc, renderer):
+    """main.rs:63-74 as checked in: test_sphere (demo_scene.rs:229-244), 800 x 400, 128 samples per pixel, MAX_DEPTH 50 — at its
+    own size against the oracle: ray counts per depth exact, no pixel off by more than 1e-4, RGB8 within one level."""
+    scene = rt.Scene.build("test_sphere", 800 / 400)
+    renderer.upload(scene)
+    p = rt.make_params(800, 400, 128, max_depth=50, seed=95)
+    img, rgb8, st = renderer.render(scene.camera, p, want_rgb8=True)
+    ref, ref8, so = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_COUNTER), want_rgb8=True)
+    assert st.n_paths == 800 * 400 * 128 and st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
+    assert 1.7 < st.n_rays / st.n_paths < 1.8
+    _compare_frames(orc, scene, p, img, ref, "test_sphere 800x400x128", rt, renderer)
+    assert np.abs(rgb8.astype(np.int16) - ref8.astype(np.int16)).max() <= 1
+
+
+def test_c_host_through_the_headers(rt, renderer, tmp_path):
+    """examples/host_main.c — C99, nothing but include/rtow_host.h and include/rtow_mi355x.h, the stand-in for a host in the
+    reference's own language (main.rs:62-129) — run as a child process: scene function, context, upload, rt_render into
+    rt_host_alloc'ed memory, PNG.  Its RGB8 image equals the ctypes path's byte for byte, on the reference's shipped workload
+    (small) and on sphere_scene, whose image texture it registers from a decoded PPM."""
+    import subprocess
+    from PIL import Image
+    from ray_tracing_in_one_weekend_amd import images
+    exe = os.path.join(ROOT, "build", "host_main")
+    assert os.path.exists(exe), "build/host_main is missing: python -c 'import __graft_entry__ as g; g.build()'"
+    for rel in images.DEFAULT_IMAGES:  # the same decode the ctypes path registers (PIL), handed over as 8-bit P6
+        with Image.open(os.path.join(images.ASSET_DIR, rel)) as im:
+            a = np.asarray(im.convert("RGB"), dtype=np.uint8)
+        with open(tmp_path / (os.path.splitext(os.path.basename(rel))[0] + ".ppm"), "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (a.shape[1], a.shape[0]) + a.tobytes())
+    for name, nx, ny, spp, depth in (("test_sphere", 200, 100, 16, 50), ("sphere_scene", 320, 180, 8, 50)):
+        png, raw = tmp_path / f"{name}.png", tmp_path / f"{name}.rgb8"
+        r = subprocess.run([exe, name, str(nx), str(ny), str(spp), str(depth), str(png), str(raw), str(tmp_path)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "Mray/s" in r.stdout and f"saved {png}" in r.stdout
+        scene = rt.Scene.build(name, nx / ny)
+        renderer.upload(scene)
+        _, rgb8, st = renderer.render(scene.camera, rt.make_params(nx, ny, spp, max_depth=depth, seed=95), want_rgb8=True)
+        got = np.fromfile(raw, dtype=np.uint8).reshape(ny, nx, 3)
+        assert np.array_equal(got, rgb8), name
+        assert f"{st.n_rays} rays" in r.stdout
+        with Image.open(png) as im:
+            assert np.array_equal(np.asarray(im.convert("RGB")), rgb8)
+
+
 def _primary_rays(scene, p, pix_i, pix_j, samp):
     """main.rs:89-94 + camera.rs:40-46 for the given (pixel, sample) pairs in numpy float32, every operation rounded once
     (glam order: dot = (xx + yy) + zz, normalize = v * (1 / len)) — the very rays the renderer and the oracle trace."""
@@ -522,27 +578,31 @@ def _texel_edge_distance(scene, hit, o, d, t):
     return min(abs(x - round(x)) / fs.img_w[img], abs(y - round(y)) / fs.img_h[img]) * 2.0 ** 23
 
 
-def _explain_image_outliers(rt, orc, renderer, scene, p, img, it, name, px_tol=1e-4, edge_ulps=2.0):
-    """texture.rs:183-193 / hitable.rs:65-71: `(u * W) as u32` of a uv that went through acos and atan2.  Device and host libm
-    differ in the last ulp there, so a lookup that lands within a few ulp of a texel edge picks the neighbouring texel on one
-    side — a visible, isolated pixel difference that no tolerance on the arithmetic can cover.  This makes that explanation a
-    tested statement: every pixel that differs from the iterative oracle by more than `px_tol` (display units) is re-traced
-    sample by sample and bounce by bounce through rt_debug_bounce on BOTH sides; the two must agree bit for bit in hit, t and
-    scattered ray at every bounce, and wherever their colours part the segment must be an image lookup whose (u W, v H) lies
-    within `edge_ulps` * 2^-23 of a texel edge in (u, v).  A pixel without such a sample fails the test.
-    Returns the outlier mask."""
+def _explain_outliers(rt, orc, renderer, scene, p, img, it, name, px_tol=1e-4, edge_ulps=2.0):
+    """Every pixel that differs from the iterative oracle by more than `px_tol` (display units) must be EXPLAINED by one of the
+    two places where device and host libm differ in the last ulp; a pixel that is not fails the test.  All samples of such
+    a pixel are re-traced bounce by bounce through rt_debug_bounce on BOTH sides (primary rays rebuilt in numpy float32, bit for
+    bit); hit, alive flag and scattered direction must agree exactly at every bounce, t and the scattered origin too — except
+      * a medium scatter (hitable.rs:560-570: `neg_inv_density * ln(rand)`): t may differ in the last bits (2e-6).  The scatter
+        POINT is then an ulp apart, every later comparison on that path sees different inputs and the two paths may part for
+        good (cornell_box: about one path in 350 000), so the path is followed no further;
+      * an image lookup (texture.rs:183-193 / hitable.rs:65-71: `(u * W) as u32` of a uv that went through acos and atan2):
+        where the colours of a segment part, (u W, v H) must lie within `edge_ulps` * 2^-23 of a texel edge in (u, v) — the
+        neighbouring texel on one side, a visible, isolated difference that no tolerance on the arithmetic can cover.
+    Returns (outlier mask, diverged medium paths, texel-edge lookups)."""
     fin = np.isfinite(it) & np.isfinite(img)
     diff = np.abs(display(np.where(fin, img, 0)) - display(np.where(fin, it, 0))).max(axis=2)
     out = diff > px_tol
     jj, ii = np.nonzero(out)
-    assert len(jj) <= max(64, int(2e-4 * out.size)), (name, len(jj))  # isolated pixels, not a region
+    assert len(jj) <= max(64, int(1e-3 * out.size)), (name, len(jj))  # isolated pixels, not a region
     if not len(jj):
-        return out
+        return out, 0, 0
+    n_prims = scene.flat.n_spheres + scene.flat.n_rects
     pi_, pj_ = np.repeat(ii, p.spp), np.repeat(jj, p.spp)
-    ps_ = np.tile(np.arange(p.spp), len(ii))
-    o, d, keys = _primary_rays(scene, p, pi_, pj_, ps_)
+    o, d, keys = _primary_rays(scene, p, pi_, pj_, np.tile(np.arange(p.spp), len(ii)))
     live = np.ones(len(o), dtype=bool)
-    explained = np.zeros(len(o), dtype=bool)
+    medium = np.zeros(len(o), dtype=bool)
+    texel = np.zeros(len(o), dtype=bool)
     worst = 0.0
     for depth in range(p.max_depth + 1):
         idx = np.nonzero(live)[0]
@@ -552,71 +612,36 @@ def _explain_image_outliers(rt, orc, renderer, scene, p, img, it, name, px_tol=1
         c = orc.debug_bounce(scene.flat_ptr, o[idx], d[idx], keys[idx], depth=depth, accel=orc.ACCEL_LIST)
         for k in ("hit", "alive"):
             assert np.array_equal(g[k], c[k]), (name, depth, k)
-        for k in ("t", "o", "d"):
-            assert np.array_equal(g[k].view(np.uint32), c[k].view(np.uint32)), (name, depth, k)
-        for r in range(len(idx)):
-            a = np.concatenate([g["radiance"][r], g["attenuation"][r]]).astype(np.float64)
-            b = np.concatenate([c["radiance"][r], c["attenuation"][r]]).astype(np.float64)
-            if np.allclose(a, b, rtol=2e-5, atol=1e-6):
+        assert np.array_equal(g["d"].view(np.uint32), c["d"].view(np.uint32)), (name, depth, "d")
+        exact = (g["t"].view(np.uint32) == c["t"].view(np.uint32)) & (g["o"].view(np.uint32) == c["o"].view(np.uint32)).all(axis=1)
+        for r in np.nonzero(~exact)[0]:  # an ulp apart: only a medium scatter may be
+            assert g["hit"][r] >= n_prims and np.isclose(g["t"][r], c["t"][r], rtol=2e-6), \
+                (name, "pixel", int(pi_[idx[r]]), int(pj_[idx[r]]), "depth", depth, int(g["hit"][r]), g["t"][r], c["t"][r])
+            medium[idx[r]] = True
+        for r in np.nonzero(exact)[0]:
+            a_ = np.concatenate([g["radiance"][r], g["attenuation"][r]]).astype(np.float64)
+            b_ = np.concatenate([c["radiance"][r], c["attenuation"][r]]).astype(np.float64)
+            if np.allclose(a_, b_, rtol=2e-5, atol=1e-6, equal_nan=True):
                 continue
             dist = _texel_edge_distance(scene, int(g["hit"][r]), o[idx[r]], d[idx[r]], g["t"][r])
-            assert dist is not None and dist <= edge_ulps, (name, "pixel", int(pi_[idx[r]]), int(pj_[idx[r]]), "depth", depth, "colours differ away from a texel edge", dist, a, b)
-            explained[idx[r]] = True
+            assert dist is not None and dist <= edge_ulps, (name, "pixel", int(pi_[idx[r]]), int(pj_[idx[r]]), "depth", depth,
+                                                            "colours differ away from a texel edge", dist, a_, b_)
+            texel[idx[r]] = True
             worst = max(worst, dist)
-        alive = g["alive"].astype(bool)
+        alive = g["alive"].astype(bool) & exact
         o[idx[alive]], d[idx[alive]] = g["o"][alive], g["d"][alive]
         live[idx[~alive]] = False
-    per_pixel = explained.reshape(len(ii), p.spp).any(axis=1)
-    assert per_pixel.all(), (name, "pixels that differ without a texel-edge lookup on any of their paths", list(zip(ii[~per_pixel], jj[~per_pixel]))[:8])
-    print(f"{name}: {len(ii)} of {out.size} pixels differ by more than {px_tol}; each holds a lookup within {worst:.2f} x 2^-23 of a texel edge")
-    return out
-
-
-def _explain_medium_outliers(rt, orc, renderer, scene, p, img, it, name, px_tol=1e-4):
-    """hitable.rs:560-570: a medium's scatter distance is `neg_inv_density * ln(rand)`, and device and host libm differ in
-    the last ulp of ln (the per-bounce tests hold medium hits to 2e-6, everything else bit for bit).  The scatter POINT then
-    differs by an ulp, and every comparison further down that path — a silhouette, a box edge, a dielectric coin flip —
-    sees inputs an ulp apart: now and then one goes the other way and the two paths part for good (cornell_box: about one
-    path in 350 000).  This makes that a tested statement: every pixel that differs from the iterative oracle by more than
-    `px_tol` is re-traced sample by sample through rt_debug_bounce on both sides, and the FIRST bounce at which the two
-    disagree in anything but the last bits must be a medium scatter whose t agrees to 2e-6 (after which the inputs differ and
-    nothing more can be said).  Returns (outlier mask, number of diverged paths)."""
-    fin = np.isfinite(it) & np.isfinite(img)
-    diff = np.abs(display(np.where(fin, img, 0)) - display(np.where(fin, it, 0))).max(axis=2)
-    out = diff > px_tol
-    jj, ii = np.nonzero(out)
-    assert len(jj) <= max(16, int(1e-3 * out.size)), (name, len(jj))
-    n_prims = scene.flat.n_spheres + scene.flat.n_rects
-    diverged = 0
-    for pj, pi in zip(jj, ii):
-        o, d, keys = _primary_rays(scene, p, np.full(p.spp, pi), np.full(p.spp, pj), np.arange(p.spp))
-        live = np.ones(p.spp, dtype=bool)
-        seen = False
-        for depth in range(p.max_depth + 1):
-            idx = np.nonzero(live)[0]
-            if not len(idx):
-                break
-            g = renderer.debug_bounce(o[idx], d[idx], keys[idx], depth=depth)
-            c = orc.debug_bounce(scene.flat_ptr, o[idx], d[idx], keys[idx], depth=depth, accel=orc.ACCEL_LIST)
-            assert np.array_equal(g["hit"], c["hit"]) and np.array_equal(g["alive"], c["alive"]), (name, pi, pj, depth)
-            assert np.array_equal(g["d"].view(np.uint32), c["d"].view(np.uint32)), (name, pi, pj, depth)
-            exact = np.array([np.array_equal(g["t"][k:k + 1].view(np.uint32), c["t"][k:k + 1].view(np.uint32)) and
-                              np.array_equal(g["o"][k].view(np.uint32), c["o"][k].view(np.uint32)) for k in range(len(idx))])
-            for k in np.nonzero(~exact)[0]:  # an ulp apart: only a medium scatter may be, and the path is followed no further
-                assert g["hit"][k] >= n_prims and np.isclose(g["t"][k], c["t"][k], rtol=2e-6), (name, pi, pj, depth, g["hit"][k], g["t"][k], c["t"][k])
-                seen = True
-                diverged += 1
-            alive = g["alive"].astype(bool) & exact
-            o[idx[alive]], d[idx[alive]] = g["o"][alive], g["d"][alive]
-            live[idx[~alive]] = False
-        assert seen, (name, "pixel", int(pi), int(pj), "differs although none of its paths scatters in a medium an ulp apart")
-    print(f"{name}: {len(jj)} of {out.size} pixels differ by more than {px_tol}; each holds a path whose medium scatter point is an ulp apart ({diverged} such paths)")
-    return out, diverged
+    per_pixel = (medium | texel).reshape(len(ii), p.spp).any(axis=1)
+    assert per_pixel.all(), (name, "pixels that differ although none of their paths holds a medium scatter an ulp apart or a texel-edge lookup",
+                             list(zip(ii[~per_pixel], jj[~per_pixel]))[:8])
+    print(f"{name}: {len(ii)} of {out.size} pixels differ by more than {px_tol}: {int(medium.sum())} paths with a medium scatter point an ulp "
+          f"apart, {int(texel.sum())} lookups within {worst:.2f} x 2^-23 of a texel edge")
+    return out, int(medium.sum()), int(texel.sum())
 
 
 def _rays_agree(st, so, scene, p):
     """Ray counts per depth: exact — except in a scene with media, where a path whose scatter point is an ulp apart may part from
-    the oracle's (_explain_medium_outliers): there to 1e-4 of the rays, as test_constant_medium_and_cornell_box states it."""
+    the oracle's (_explain_outliers): there to 1e-4 of the rays, as test_constant_medium_and_cornell_box states it."""
     if not scene.flat.n_media:
         assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
     else:
@@ -626,22 +651,23 @@ def _rays_agree(st, so, scene, p):
 def _compare_frames(orc, scene, p, img, ref, name, rt=None, renderer=None):
     """Frame against the oracle when pixels may be non-finite (pbr.rs: a grazing n_dot_i -> 0 divides by ~0, the
     attenuation overflows and inf * 0 = NaN poisons the pixel in the reference's arithmetic too).
-    Against the oracle in the wavefront's own product order (EST_ITERATIVE) the non-finite pixels must be THE SAME
-    pixels and the finite ones agree to 2e-5.  In a scene with image textures the pixels that differ by more than 1e-4
-    are first shown, one by one, to hold a lookup within a few ulp of a texel edge (_explain_image_outliers: device and
-    host libm differ in the last ulp of acos / atan2) and the 2e-5 bound then holds on all the others; against the
-    reference's recursive order an overflow can strike at a different factor of the chain, so there only the pixels
-    finite in both are compared (RMSE_TOL) and the two masks may differ in a 1e-4 fraction of the pixels at most."""
-    it, _, _ = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_COUNTER, estimator=orc.EST_ITERATIVE))
+    Against the oracle in the wavefront's own product order (EST_ITERATIVE; list walk for scenes with rectangles, whose
+    unpadded reference boxes lose grazing hits) the non-finite pixels must be THE SAME pixels and the finite ones agree to
+    2e-5 RMSE with no pixel off by more than 1e-4 — in a scene with media or image textures every pixel beyond that is first
+    re-traced and explained (_explain_outliers), in any other scene there is none; against the reference's recursive order an
+    overflow can strike at a different factor of the chain, so there only the pixels finite in both are compared (RMSE_TOL)
+    and the two masks may differ in a 1e-4 fraction of the pixels at most."""
+    it, _, _ = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_COUNTER, estimator=orc.EST_ITERATIVE, accel=_accel_for(orc, scene)))
     assert np.array_equal(np.isfinite(img), np.isfinite(it)), name
     fin = np.isfinite(it)
-    if scene.flat.n_media:
-        assert renderer is not None, "scenes with media need the renderer to re-trace their outliers"
-        fin = fin & ~_explain_medium_outliers(rt, orc, renderer, scene, p, img, it, name)[0][:, :, None]
-        ref = np.where(fin, ref, img)  # (the same pixels are set aside against the recursive order below)
-    elif scene.flat.n_images:
-        assert renderer is not None, "scenes with image textures need the renderer to re-trace their outliers"
-        fin = fin & ~_explain_image_outliers(rt, orc, renderer, scene, p, img, it, name)[:, :, None]
+    if scene.flat.n_media or scene.flat.n_images:
+        assert renderer is not None, "scenes with media or image textures need the renderer to re-trace their outliers"
+        fin = fin & ~_explain_outliers(rt, orc, renderer, scene, p, img, it, name)[0][:, :, None]
+        if scene.flat.n_media:
+            ref = np.where(fin, ref, img)  # (the same pixels are set aside against the recursive order below)
+    else:
+        worst = np.abs(display(np.where(fin, img, 0)) - display(np.where(fin, it, 0))).max(initial=0.0)
+        assert worst <= 1e-4, (name, worst)  # nothing to explain them with: no pixel may be off
     e_it = rmse_display(np.where(fin, img, 0), np.where(fin, it, 0))
     assert e_it <= 2e-5, (name, e_it)
     both = np.isfinite(ref) & np.isfinite(img)
@@ -923,9 +949,9 @@ def test_russian_roulette_opt_in(rt, orc, renderer):
     it, _, si = _oracle(orc, scene, p, estimator=orc.EST_ITERATIVE)
     assert st.n_rays == so.n_rays == si.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
     # (sphere_scene holds an image-textured sphere: pixels with a lookup on a texel edge are shown to be just that and set
-    # aside, _explain_image_outliers; the re-trace follows the path's own draws, which roulette leaves untouched — it takes
+    # aside, _explain_outliers; the re-trace follows the path's own draws, which roulette leaves untouched — it takes
     # the counter after them, DESIGN.md "RNG")
-    keep = ~_explain_image_outliers(rt, orc, renderer, scene, p, img, it, "sphere_scene + russian roulette")[:, :, None]
+    keep = ~_explain_outliers(rt, orc, renderer, scene, p, img, it, "sphere_scene + russian roulette")[0][:, :, None]
     assert rmse_display(np.where(keep, img, 0), np.where(keep, it, 0)) <= 2e-5 and rmse_display(img, ref) <= RMSE_TOL
     plain, _, sp = renderer.render(scene.camera, rt.make_params(320, 180, 16, max_depth=50))
     assert st.n_rays < 0.9 * sp.n_rays
@@ -1144,9 +1170,8 @@ def test_constant_medium_and_cornell_box(rt, orc, renderer):
     p = rt.make_params(200, 200, 16, max_depth=50)
     img, _, st = renderer.render(scene.camera, p)
     ref, _, so = _oracle(orc, scene, p, accel=orc.ACCEL_LIST)
-    assert abs(int(st.n_rays) - int(so.n_rays)) / so.n_rays < 1e-4
-    assert (np.abs(display(img) - display(ref)).max(axis=2) > 1e-3).mean() < 2e-3
-    assert abs(img.mean() - ref.mean()) / ref.mean() < 1e-3
+    _rays_agree(st, so, scene, p)
+    _compare_frames(orc, scene, p, img, ref, "cornell_box", rt, renderer)  # every pixel to 1e-4 unless re-traced and explained
     # sharding and slicing stay bit-invariant with media (the medium draw is keyed like every other draw)
     from ray_tracing_in_one_weekend_amd import shard
     parts = [renderer.render(scene.camera, rt.make_params(200, 200, 16, max_depth=50, shard_band=8, shard_count=2, shard_id=r, spp_slice=5))[0]
@@ -1204,8 +1229,8 @@ def test_final_scene(rt, orc, renderer):
     p = rt.make_params(160, 160, 8, max_depth=50)
     img, _, st = renderer.render(scene.camera, p)
     ref, _, so = _oracle(orc, scene, p, accel=orc.ACCEL_LIST)
-    assert abs(int(st.n_rays) - int(so.n_rays)) / so.n_rays < 1e-4
-    assert (np.abs(display(img) - display(ref)).max(axis=2) > 1e-3).mean() < 2e-3
+    _rays_agree(st, so, scene, p)
+    _compare_frames(orc, scene, p, img, ref, "final_scene", rt, renderer)  # medium scatters an ulp apart AND texel-edge lookups, each re-traced
     assert abs(img.mean() - ref.mean()) / ref.mean() < 1e-3
 
 
@@ -1396,5 +1421,5 @@ def test_random_scenes_bounce_parity(rt, orc, renderer, seed):
     p = rt.make_params(96, 64, 4, max_depth=6)
     img, _, st = renderer.render(scene.camera, p)
     ref, _, so = _oracle(orc, scene, p, accel=orc.ACCEL_LIST)
-    assert abs(int(st.n_rays) - int(so.n_rays)) <= max(2, int(2e-4 * so.n_rays))
-    assert (np.abs(display(img) - display(ref)).max(axis=2) > 2e-3).mean() < 5e-3
+    _rays_agree(st, so, scene, p)  # exact per depth unless the scene holds a medium
+    _compare_frames(orc, scene, p, img, ref, f"random scene {seed}", rt, renderer)  # no medium, no image: no pixel may be off
