@@ -55,6 +55,7 @@ struct RtCtx {
     size_t isect_lds = 0;      // k_intersect: nodes + geometry (when they fit) + stack levels + counters
     bool bvh_in_lds = false;   // false: the tree is traversed out of HBM/L2, only the stacks are in LDS
     bool general_lds = false;  // k_intersect<.., GLDS>: the wrapper / medium tables of a general scene are staged in LDS
+    bool general_kernels = false; // the general instantiations (rectangles, wrappers, media — or RT_OPT_GENERAL_KERNELS at upload)
     bool use_grid = false;     // sphere-only scene with a uniform grid (rt_grid.h): depth >= 1 runs k_intersect_grid
     GridParams grid{};
     size_t grid_lds = 0;
@@ -145,9 +146,7 @@ struct StepBuffers {
     unsigned long long* totals;
     const GenParams* gpd;
 };
-bool scene_is_general(const RtCtx* ctx) {
-    return ctx->opt[RT_OPT_GENERAL_KERNELS] == 1u || ctx->ds.n_rects > 0 || ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0;
-}
+bool scene_is_general(const RtCtx* ctx) { return ctx->general_kernels; }
 bool grid_enabled(const RtCtx* ctx) { return ctx->use_grid && ctx->opt[RT_OPT_GRID] != 1u && !scene_is_general(ctx); }
 bool scene_perlin_lds(const RtCtx* ctx) { return ctx->ds.n_perlin > 0 && ctx->ds.n_perlin <= RT_PERLIN_LDS_MAX_SETS; }
 
@@ -764,7 +763,8 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     // with tree AND wrapper tables in LDS and one (profiles/round3/final_like.txt) — which is also why final_scene's tree was
     // not squeezed into LDS with quantised boxes: 1 150 nodes x 48 B + 56 KB of stacks leave room for one workgroup only.
     // Sphere-only scenes keep their faster LDS-only kernel (sorted slab planes) even at one workgroup per CU.
-    const bool general = ds.n_rects > 0 || ds.n_xforms > 0 || ds.n_media > 0;
+    const bool general = ds.n_rects > 0 || ds.n_xforms > 0 || ds.n_media > 0 || ctx->opt[RT_OPT_GENERAL_KERNELS] == 1u;
+    ctx->general_kernels = general;
     const size_t lds_budget = general ? ctx->lds_limit / 2 : ctx->lds_limit;
     ctx->bvh_in_lds = bvh_ok && bvh_lds_bytes(ds, RT_BVH_BLOCK, true) <= lds_budget && !force_hbm;
     ctx->isect_lds = bvh_lds_bytes(ds, RT_BVH_BLOCK, ctx->bvh_in_lds);

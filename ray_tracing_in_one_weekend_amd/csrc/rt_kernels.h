@@ -995,7 +995,11 @@ template <bool PERLIN_LDS, bool GEN, bool RECTS>
                        // sphere scenes; in the production frame, where the two chains overlap, its dispatches last 12.3 ms instead
                        // of 10.3 and the frame takes the same 56.5 ms (profiles/round3/ab_gen_waves.txt): left at 4
 #endif
-__global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : 4) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
+#ifndef RT_SORTED_WAVES
+#define RT_SORTED_WAVES 4 // waves per SIMD the depth >= 1 instantiations are compiled for (5 / 6, with and without the pbr.rs
+                          // materials: no gain, profiles/round4/ab_shade_waves_*.txt)
+#endif
+__global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_shade(DevScene sc, Queue qin, const float2* __restrict__ qh, Queue qout,
                                                const uint32_t* __restrict__ in_counts, uint32_t* __restrict__ out_counts,
                                                float* __restrict__ rad, ShadeParams tp,
                                                unsigned long long* __restrict__ stats,
