@@ -7,9 +7,9 @@ scene = rt.Scene.build("sphere_scene", 16/9)
 r = rt.Renderer(0); r.upload(scene)
 p = rt.make_params(1920, 1080, 256, max_depth=50)
 a,_,sa = r.render(scene.camera, p)
-os.environ["RTOW_NO_PRIMARY_LISTS"]="1"
+r.set_option("primary_lists", 1)
 b,_,sb = r.render(scene.camera, p)
-os.environ.pop("RTOW_NO_PRIMARY_LISTS")
+r.set_option("primary_lists", 0)
 pb = rt.make_params(1920, 1080, 256, max_depth=50, flags=rt._ffi.FLAG_BRUTE_FORCE)
 c,_,sc = r.render(scene.camera, pb)
 print("lists", sa.n_rays, "tree", sb.n_rays, "brute", sc.n_rays)

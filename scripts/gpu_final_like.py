@@ -1,6 +1,6 @@
 """A final_scene-like general scene of adjustable size (demo_scene.rs:150-221: box field of GBoxes, an instanced cloud of spheres
 under Translate(RotateY(..)), a light, a few big spheres) rendered with its tree in LDS and with the same tree read through
-L2 (RTOW_BVH_HBM=1, as the real final_scene must): what would final_scene gain from a tree that fits LDS?
+L2 (rt_debug_set_option tree_placement = 1, as the real final_scene must): what would final_scene gain from a tree that fits LDS?
     python scripts/gpu_final_like.py <boxes_per_side> <cloud_spheres> [spp] [rounds]"""
 import os
 import statistics
@@ -37,13 +37,11 @@ s.set_camera((478, 278, -600), (278, 278, 0), (0, 1, 0), 40.0, 1.0)
 s.finish()
 print(f"boxes {nb}x{nb}, cloud {nc}: {s.flat.n_spheres} spheres, {s.flat.n_rects} rects, {s.flat.n_xforms} wrappers")
 rends = []
-for label, env in (("default placement", {}), ("tree through L2 (RTOW_BVH_HBM=1)", {"RTOW_BVH_HBM": "1"}), ("default again", {})):
-    for k, v in env.items():
-        os.environ[k] = v
+for label, opts in (("default placement", {}), ("tree through L2 (tree_placement = 1)", {"tree_placement": 1}), ("default again", {})):
     r = rt.Renderer(0)
+    for k, v in opts.items():
+        r.set_option(k, v)
     r.upload(s)
-    for k in env:
-        os.environ.pop(k, None)
     rends.append((label, r))
 p = rt.make_params(1080, 1080, spp, max_depth=50, flags=_ffi.FLAG_TIME_DEPTHS)
 res = {i: [] for i in range(len(rends))}

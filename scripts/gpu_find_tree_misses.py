@@ -8,10 +8,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ray_tracing_in_one_weekend_amd as rt
 
-os.environ["RTOW_NO_PRIMARY_LISTS"] = "1"
 rt.register_default_images()
 scene = rt.Scene.build("sphere_scene", 16 / 9)
 r = rt.Renderer(0)
+r.set_option("primary_lists", 1)  # depth 0 through the tree
+r.set_option("grid", 1)           # ... and every other depth too
 r.upload(scene)
 nx, ny, spp, seed = 1920, 1080, 256, 95
 nb = (ny + 7) // 8

@@ -1,4 +1,6 @@
-"""Round-3 what-if probes on one GPU, one process (interleaved, same-binary switches where possible):
+"""(ROUND 3 RECORD: the reorder what-if needs the RT_WHATIF_REORDER build of scripts/experiments/whatif_switches_and_reorder_pass.patch, whose
+library still reads RTOW_WHATIF_REORDER; the product library reads no environment variable.  `treemem` uses rt_debug_set_option.)
+Round-3 what-if probes on one GPU, one process (interleaved, same-binary switches where possible):
     python scripts/gpu_r3_probe.py reorder  <lib_reorder.so> [spp] [rounds] [scene]   secondary-ray coherence what-if (RTOW_WHATIF_REORDER)
     python scripts/gpu_r3_probe.py lanes    <lib_reorder_lanes.so> [spp] [scene]      lane statistics of the same, + the Perlin section at depth 0
     python scripts/gpu_r3_probe.py treemem  <lib.so> [spp] [rounds] [scene]           tree in LDS against the same tree read through L2 (RTOW_BVH_HBM)
@@ -117,15 +119,13 @@ elif what == "treemem":
     name = sys.argv[5] if len(sys.argv) > 5 else "sphere_scene"
     scene = rt.Scene.build(name, 16 / 9)
     rends = []
-    for label, env in (("tree + geometry in LDS", None), ("tree + geometry read through L2 (RTOW_BVH_HBM=1)", "1"), ("LDS again", None)):
-        if env:
-            os.environ["RTOW_BVH_HBM"] = env
-        else:
-            os.environ.pop("RTOW_BVH_HBM", None)
+    for label, env in (("tree + geometry in LDS", None), ("tree + geometry read through L2 (tree_placement = 1)", "1"), ("LDS again", None)):
         r = load(path) if not rends else rt.Renderer(0)
+        r.set_option("grid", 1)  # the tree at every depth
+        if env:
+            r.set_option("tree_placement", 1)
         r.upload(scene)
         rends.append((label, r))
-    os.environ.pop("RTOW_BVH_HBM", None)
     p = rt.make_params(1920, 1080, spp, max_depth=50, flags=_ffi.FLAG_TIME_DEPTHS)
     res = {i: [] for i in range(len(rends))}
     for it in range(rounds + 1):
