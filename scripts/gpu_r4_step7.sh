@@ -1,0 +1,12 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out/r4
+timeout -k 10 600 python -m pytest tests -x -q -m gpu > gpurun_out/r4/pytest_step7.log 2>&1
+rc=$?; echo "pytest rc=$rc" >> gpurun_out/r4/pytest_step7.log; tail -3 gpurun_out/r4/pytest_step7.log
+[ $rc = 0 ] || exit 1
+python scripts/gpu_ab.py 128 5 build/librtow_prev2.so - build/librtow_prev2.so - > gpurun_out/r4/ab_step7.txt 2>&1
+cat gpurun_out/r4/ab_step7.txt
+RTOW_AB_FLAGS=0 python scripts/gpu_ab.py 256 5 build/librtow_prev2.so - build/librtow_prev2.so - > gpurun_out/r4/ab_step7_frame.txt 2>&1
+cat gpurun_out/r4/ab_step7_frame.txt
+RTOW_SCENE=pbr_sweep_scene python scripts/gpu_ab.py 128 3 build/librtow_prev2.so - build/librtow_prev2.so - > gpurun_out/r4/ab_step7_pbr.txt 2>&1
+cat gpurun_out/r4/ab_step7_pbr.txt
