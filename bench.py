@@ -268,7 +268,7 @@ def build_record(*, config_id, cfg, nx, ny, spp, spp_total, scaling, max_depth, 
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload,
-                   "paths_per_step": int(r0.get("n_paths", 0)) * world, "rays_per_step_rank0": int(r0.get("n_rays", 0)),
+                   "paths_per_step": nx * ny * spp_total, "rays_per_step_rank0": int(r0.get("n_rays", 0)),
                    "rays_per_path": round(r0.get("n_rays", 0) / max(r0.get("n_paths", 0), 1), 4),
                    "texture_fetches_per_step_rank0": int(r0.get("n_texture_fetches", 0)),
                    "spp_slices": int(r0.get("n_slices", 0))},

@@ -395,6 +395,15 @@ typedef struct RtSceneInfo {
 } RtSceneInfo;
 int rt_debug_scene_info(const RtCtx* ctx, RtSceneInfo* info);
 
+/* The uniform grid rt_scene_upload would build over the spheres of `scene` (host code only: no context, no GPU), for tests of
+ * its construction.  cell_per_mille as RT_OPT_GRID_CELL (0 = default), lds_budget in bytes (0 = 80 KiB, two workgroups per CU).
+ * Returns RT_ERR_UNSUPPORTED when the scene gets no grid, RT_ERR_INVALID when a buffer is too small (the needed sizes are
+ * then in *n_cells / *n_refs), else RT_OK with: grid[0..2] = min corner, grid[3..5] = cell edges, grid[6] = pad, grid[7] =
+ * origin-coordinate limit; dims[0..2] = cells per axis; cells[c] = offset << 12 | count (x fastest); refs = sphere ids of the
+ * cell lists; large[0..*n_large) = the spheres tested for every ray. */
+int rt_debug_grid_build(const RtFlatScene* scene, uint32_t cell_per_mille, uint32_t lds_budget, float grid[8], uint32_t dims[3],
+                        uint32_t* cells, uint32_t* n_cells, uint16_t* refs, uint32_t* n_refs, uint32_t large[4], uint32_t* n_large);
+
 #ifdef RT_PROFILE_LANES
 /* Diagnostic builds only (-DRT_PROFILE_LANES; absent from the product library): the lane-occupancy counters of
  * csrc/rt_kernels.h, optionally reset after reading. */

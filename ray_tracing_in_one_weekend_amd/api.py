@@ -179,6 +179,28 @@ class Scene:
             pass
 
 
+def grid_build(scene, cell_per_mille=0, lds_budget=0):
+    """rt_debug_grid_build (host code of the GPU library, no GPU): the uniform grid rt_scene_upload would build over the spheres
+    of `scene`, or None when the scene gets none.  -> dict(origin[3], cell[3], pad, max_coord, dims[3], cells u32 [nz, ny, nx]
+    (offset << 12 | count), refs u16, large: list)."""
+    lib = _ffi.load_gpu_library()
+    ptr = scene.flat_ptr if isinstance(scene, Scene) else C.pointer(scene)
+    grid, dims, large = (C.c_float * 8)(), (C.c_uint32 * 3)(), (C.c_uint32 * 4)()
+    nc, nr, nl = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    rc = lib.rt_debug_grid_build(ptr, cell_per_mille, lds_budget, grid, dims, None, C.byref(nc), None, C.byref(nr), large, C.byref(nl))
+    if rc == -4:  # RT_ERR_UNSUPPORTED: no grid for this scene
+        return None
+    cells = np.zeros(max(nc.value, 1), np.uint32)
+    refs = np.zeros(max(nr.value, 1), np.uint16)
+    rc = lib.rt_debug_grid_build(ptr, cell_per_mille, lds_budget, grid, dims, cells.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(nc),
+                                 refs.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(nr), large, C.byref(nl))
+    if rc != 0:
+        raise RtError(f"rt_debug_grid_build failed ({rc})")
+    d = [int(x) for x in dims]
+    return {"origin": np.array(grid[0:3], np.float32), "cell": np.array(grid[3:6], np.float32), "pad": float(grid[6]), "max_coord": float(grid[7]),
+            "dims": d, "cells": cells[:nc.value].reshape(d[2], d[1], d[0]), "refs": refs[:nr.value], "large": [int(large[k]) for k in range(nl.value)]}
+
+
 def make_params(nx, ny, spp, max_depth=50, seed=95, shard_band=0, shard_count=1, shard_id=0, spp_slice=0, flags=0):
     p = RtParams()
     p.flags = flags

@@ -1116,6 +1116,33 @@ int rt_debug_get_option(const RtCtx* ctx, uint32_t option, uint32_t* value) {
     return RT_OK;
 }
 
+int rt_debug_grid_build(const RtFlatScene* s, uint32_t cell_per_mille, uint32_t lds_budget, float grid[8], uint32_t dims[3], uint32_t* cells,
+                        uint32_t* n_cells, uint16_t* refs, uint32_t* n_refs, uint32_t large[4], uint32_t* n_large) {
+    if (!s || !grid || !dims || !n_cells || !n_refs || !large || !n_large) return RT_ERR_INVALID;
+    if (s->n_rects || s->n_xforms || s->n_media || (s->n_spheres && (!s->sph_cx || !s->sph_cy || !s->sph_cz || !s->sph_r))) return RT_ERR_UNSUPPORTED;
+    std::vector<float4> geo(s->n_spheres);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        if (!std::isfinite(s->sph_cx[i]) || !std::isfinite(s->sph_cy[i]) || !std::isfinite(s->sph_cz[i]) || !std::isfinite(s->sph_r[i])) return RT_ERR_INVALID;
+        geo[i] = make_float4(s->sph_cx[i], s->sph_cy[i], s->sph_cz[i], s->sph_r[i]);
+    }
+    HostGrid hg;
+    build_sphere_grid(geo, lds_budget ? lds_budget : 80u * 1024u, (double)cell_per_mille * 1e-3, hg);
+    if (!hg.ok) return RT_ERR_UNSUPPORTED;
+    const uint32_t nc = hg.gp.n_cells, nr = hg.gp.all_rec >> RT_GRID_CNT_BITS; // (the all-spheres list behind the cell lists is not reported)
+    const bool fits = cells && refs && *n_cells >= nc && *n_refs >= nr;
+    *n_cells = nc, *n_refs = nr;
+    if (!fits) return RT_ERR_INVALID;
+    for (int k = 0; k < 3; ++k) grid[k] = hg.gp.g0[k], grid[3 + k] = hg.gp.cs[k];
+    grid[7] = hg.gp.max_coord;
+    grid[6] = hg.gp.max_coord / 1048576.0f; // pad (build_sphere_grid: max_coord = pad * 2^20)
+    dims[0] = hg.gp.nx, dims[1] = hg.gp.ny, dims[2] = hg.gp.nz;
+    std::copy(hg.cells.begin(), hg.cells.end(), cells);
+    std::copy(hg.refs.begin(), hg.refs.begin() + nr, refs);
+    *n_large = hg.gp.n_always;
+    for (uint32_t k = 0; k < hg.gp.n_always; ++k) large[k] = hg.gp.always[k];
+    return RT_OK;
+}
+
 int rt_debug_scene_info(const RtCtx* ctx, RtSceneInfo* info) {
     if (!ctx || !info) return RT_ERR_INVALID;
     std::memset(info, 0, sizeof(*info));

@@ -110,4 +110,4 @@ def test_bench_record_of_a_two_rank_run():
                              per_rank=[(0.2, 4e11), (0.25, 4e11)], rank0=r0, build_id="0" * 16)
     assert rec["value"] == 8000.0 and rec["ms_per_step"] == 250.0 and rec["gather_ms"] == 0.4 and rec["rccl_ranks"] == 2
     assert rec["roofline"]["frac"] == 0.25 and [q["frac"] for q in rec["roofline"]["per_rank"]] == [0.25, 0.2]
-    assert "RCCL all_gather" in rec["config"]["workload"] and rec["config"]["paths_per_step"] == 20
+    assert "RCCL all_gather" in rec["config"]["workload"] and rec["config"]["paths_per_step"] == 3840 * 2160 * 1024

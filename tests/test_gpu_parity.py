@@ -1423,3 +1423,25 @@ def test_random_scenes_bounce_parity(rt, orc, renderer, seed):
     ref, _, so = _oracle(orc, scene, p, accel=orc.ACCEL_LIST)
     _rays_agree(st, so, scene, p)  # exact per depth unless the scene holds a medium
     _compare_frames(orc, scene, p, img, ref, f"random scene {seed}", rt, renderer)  # no medium, no image: no pixel may be off
+
+
+def test_bench_two_ranks_render_and_gather(tmp_path):
+    """`python bench.py --gpus 2` end to end on this one GPU: the ranks start themselves, both render their interleaved bands of
+    the frame on device 0 (RTOW_DIST_BACKEND=gloo: the gather goes through host memory — the rehearsal of the RCCL run that no
+    box with two GPUs has been available for), rank 0 prints the line: config 3's workload label with the requested frame, whole-job
+    rays over the slowest rank's time, the gather time, every rank's own trace-step HBM fraction, and the config-2 leg."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RTOW_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--nx", "960", "--ny", "540",
+                        "--spp", "16"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["workload"].startswith("config 3:") and "960x540" in out["config"]["workload"]
+    assert out["config"]["paths_per_step"] == 960 * 540 * 16 and out["value"] > 0 and out["gather_ms"] > 0 and out["rccl_ranks"] == 0
+    assert len(out["roofline"]["per_rank"]) == 2 and all(0 < q["frac"] < 1 for q in out["roofline"]["per_rank"])
+    also = out["also"]
+    assert also["workload"].startswith("config 2:") and also["scaling"] == "weak" and also["value"] > 0 and len(also["roofline"]["per_rank"]) == 2
+    assert out["in_library"]["devices"] == 2  # (rt_multi_create over devices 0 and 1: fails on a one-GPU box, reported, never fatal)
