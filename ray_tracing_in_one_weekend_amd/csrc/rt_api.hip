@@ -898,6 +898,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     gp.nq = nq, gp.cap = cap;
     gp.seed_lo = (uint32_t)prm->seed, gp.seed_hi = (uint32_t)(prm->seed >> 32);
     gp.lists = nullptr;
+    gp.n_overflow = nullptr;
     {   // udiv_inv: reciprocals that keep the float quotient at or below the true one
         auto inv = [](uint32_t d) { return (float)((1.0 / (double)d) * (1.0 - 1.0 / 4194304.0)); };
         gp.inv_npix = inv(npix), gp.inv_nx = inv(nx), gp.inv_band = inv(band);
@@ -918,10 +919,13 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     // bounding spheres cover every pixel: overflow); final_scene (3 408 entries, most pixels overflow) would pay
     // 3 ms for nothing, hence the cap.
     if (use_bvh && fuse_gen && spp >= 4 && ctx->ds.n_entries > 0 && ctx->ds.n_entries <= 2048 && ctx->opt[RT_OPT_PRIMARY_LISTS] != 1u) {
-        if ((rc = ensure(ctx, ctx->lists, (size_t)npix * sizeof(uint4)))) return rc;
+        if ((rc = ensure(ctx, ctx->lists, ((size_t)npix + 1u) * sizeof(uint4)))) return rc; // + the overflow counter behind the lists
         gp.lists = (const uint4*)ctx->lists.p;
+        uint32_t* n_overflow = (uint32_t*)((uint4*)ctx->lists.p + npix);
+        gp.n_overflow = n_overflow;
+        RT_HIP(ctx, hipMemsetAsync(n_overflow, 0, sizeof(uint4), st));
         hipLaunchKernelGGL(k_primary_lists, dim3((npix + 255u) / 256u), dim3(256), (size_t)ctx->ds.n_entries * sizeof(float4) + 4u * RT_LIST_WAVE_CAP * 2u, st,
-                           ctx->ds, gp, (uint4*)ctx->lists.p);
+                           ctx->ds, gp, (uint4*)ctx->lists.p, n_overflow);
     }
 
     uint32_t n_trace_launches = 0;

@@ -64,6 +64,9 @@ struct GenParams {
     uint32_t nq, cap;
     uint32_t seed_lo, seed_hi;
     const uint4* lists;   // per-pixel candidate lists of the primary rays (k_primary_lists) or NULL
+    const uint32_t* n_overflow; // with `lists`: how many pixels have more candidates than a list holds (k_primary_lists counts them).
+                          // None, as on config 2: depth 0 of a sphere-only scene needs no k_intersect at all, and its workgroups
+                          // return before they stage anything (1.6 % of the frame's dispatch time went into skipping 530 M rays)
     float inv_npix, inv_nx, inv_band; // reciprocals rounded towards zero by 2^-22 (udiv_inv)
     // Local pixel order.  tiles_per_row = 0: row-major (pl = lj * nx + i).  Else (nx a multiple of 8): the first
     // tile_pixels = 64 * tiles_per_row * (rows / 8) pixels are enumerated in 8 x 8 tiles,
@@ -220,7 +223,7 @@ __device__ __forceinline__ bool cone_touches_sphere(V3 origin, V3 axis, float sa
     if (c_theta > 0.0f && c_sum > 0.0f) return length(cross(c, axis)) <= s_sum * dist * 1.0001f + 1e-6f * dist;
     return c_theta >= c_sum * dist - 1e-5f * dist;
 }
-__global__ __launch_bounds__(256) void k_primary_lists(DevScene sc, GenParams gp, uint4* __restrict__ lists) {
+__global__ __launch_bounds__(256) void k_primary_lists(DevScene sc, GenParams gp, uint4* __restrict__ lists, uint32_t* __restrict__ n_overflow) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* s_bs = reinterpret_cast<float4*>(smem);
     unsigned short* s_keep = reinterpret_cast<unsigned short*>(s_bs + sc.n_entries) + (threadIdx.x >> 6) * RT_LIST_WAVE_CAP;
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(256) void k_primary_lists(DevScene sc, GenParams gp
     }
     if (!active) return;
     const uint32_t head = n > RT_LIST_MAX ? RT_LIST_OVERFLOW : n;
+    if (head == RT_LIST_OVERFLOW) atomicAdd(n_overflow, 1u);
     lists[pl] = make_uint4(head | (ids[0] << 16), ids[1] | (ids[2] << 16), ids[3] | (ids[4] << 16), ids[5] | (ids[6] << 16));
 }
 
@@ -758,6 +762,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
     }
     const uint32_t total = pre[RT_ISECT_MAX_SHARDS];
     if (total == 0) return; // block-uniform
+    if (GEN && !RECTS && gpd->lists && *gpd->n_overflow == 0u) return; // every pixel has a list: k_shade<GEN> finds all closest hits of depth 0
     BvhLds L = stage_bvh<BLOCK, LDS_NODES>(sc, smem);
     if (GLDS) L.gt = stage_general<BLOCK>(sc, smem + bvh_lds_bytes(sc, BLOCK, LDS_NODES));
     uint32_t* s_work = reinterpret_cast<uint32_t*>(smem + bvh_lds_bytes(sc, BLOCK, LDS_NODES) - 16u);
