@@ -1129,6 +1129,21 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
             };
             const uint32_t j = seg + lane;
             RT_LANE_STAT(18, j < n_here);
+            // A segment of misses only — after the class sort most segments past depth 0 are (61 % of the rays of sphere_scene miss
+            // everything, and "miss" is one class): sky x throughput into the path's radiance slot and nothing else.  No path key (a
+            // miss draws no random number), no primitive record, no survivors to compact; the radiance is the one shade() returns.
+            if (!GEN && __all(j >= n_here || __float_as_int(hA.y) < 0)) {
+                if (j < n_here) {
+                    const V3 d = v3(rbA.x, rbA.y, rbA.z);
+                    V3 Lr = splat(0.0f);
+                    if (!near_one(d)) ++n_bad; // main.rs:39 assert!: the reference panics; the path is dropped
+                    else Lr = v3(rbA.w, rcA.x, rcA.y) * sky_value(sc, d, n_fetch); // L = T_n * sky, main.rs:58
+                    rad_store(rad, __float_as_uint(raA.w), Lr.x, Lr.y, Lr.z);
+                }
+                prefetch();
+                hA = hB, raA = raB, rbA = rbB, rcA = rcB;
+                continue;
+            }
             bool alive = false;
             Bounce bo;
             bo.o = bo.d = bo.attenuation = splat(0.0f);
