@@ -60,6 +60,15 @@ struct RtCtx {
     GridParams grid{};
     size_t grid_lds = 0;
     uint32_t opt[RT_OPT__COUNT] = {}; // rt_debug_set_option: per context, every setting renders the same bits
+    // How many pixels of the last frame had more primary-ray candidates than a list holds, and which frame that was: the lists
+    // are a function of (scene, camera, frame geometry), so a following frame of the same view that had none does not even launch
+    // the depth-0 closest-hit kernel (its workgroups would return at once, but only after waiting for 66 KB of LDS each behind
+    // the other chain's shading waves).  Read with the counters of a render; a render without RtStats leaves it alone.
+    struct {
+        bool valid = false;
+        RtCamera cam{};
+        uint32_t nx = 0, ny = 0, band = 0, count = 0, id = 0, n_overflow = 0;
+    } list_cache;
     // progressive preview (rt_set_progress): called from rt_render after every slice
     RtProgressFn progress_fn = nullptr;
     void* progress_user = nullptr;
@@ -104,6 +113,7 @@ void free_buf(DevBuf& b) {
 }
 
 void free_scene(RtCtx* ctx) {
+    ctx->list_cache.valid = false;
     for (void* p : ctx->scene_allocs) (void)hipFree(p);
     ctx->scene_allocs.clear();
     ctx->has_scene = false;
@@ -899,6 +909,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     gp.seed_lo = (uint32_t)prm->seed, gp.seed_hi = (uint32_t)(prm->seed >> 32);
     gp.lists = nullptr;
     gp.n_overflow = nullptr;
+    bool same_view = false; // the candidate lists of this frame are the ones list_cache describes
     {   // udiv_inv: reciprocals that keep the float quotient at or below the true one
         auto inv = [](uint32_t d) { return (float)((1.0 / (double)d) * (1.0 - 1.0 / 4194304.0)); };
         gp.inv_npix = inv(npix), gp.inv_nx = inv(nx), gp.inv_band = inv(band);
@@ -924,6 +935,9 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         uint32_t* n_overflow = (uint32_t*)((uint4*)ctx->lists.p + npix);
         gp.n_overflow = n_overflow;
         RT_HIP(ctx, hipMemsetAsync(n_overflow, 0, sizeof(uint4), st));
+        const auto& lc = ctx->list_cache;
+        same_view = lc.valid && std::memcmp(&lc.cam, cam, sizeof(RtCamera)) == 0 && lc.nx == nx && lc.ny == ny && lc.band == band &&
+                    lc.count == scount && lc.id == prm->shard_id;
         hipLaunchKernelGGL(k_primary_lists, dim3((npix + 255u) / 256u), dim3(256), (size_t)ctx->ds.n_entries * sizeof(float4) + 4u * RT_LIST_WAVE_CAP * 2u, st,
                            ctx->ds, gp, (uint4*)ctx->lists.p, n_overflow);
     }
@@ -989,7 +1003,9 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             ip.depth = depth;
             ip.q0 = q0, ip.q1 = q1;
             const StepBuffers sb{qi, qo, qhit, cin, cout, rad, totals, gpd};
-            launch_intersect(ctx, sg, use_bvh, gen, isect_grid_g, sb, ip);
+            // depth 0 of a sphere-only scene whose pixels all have a candidate list: k_shade<GEN> finds every closest hit itself
+            const bool no_primary_trace = gen && !rects && gp.lists != nullptr && same_view && ctx->list_cache.n_overflow == 0u;
+            if (!no_primary_trace) launch_intersect(ctx, sg, use_bvh, gen, isect_grid_g, sb, ip);
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[3 * (size_t)depth + 1], st));
             // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
             const ShadeParams sp{nq, cap, depth, prm->max_depth, depth > 0 ? 1u : 0u,
@@ -1038,6 +1054,12 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         RT_HIP(ctx, hipStreamSynchronize(st));
         std::vector<unsigned long long> h((size_t)n_depths + 2);
         RT_HIP(ctx, hipMemcpy(h.data(), totals, totals_bytes, hipMemcpyDeviceToHost));
+        if (gp.n_overflow) {
+            auto& lc = ctx->list_cache;
+            RT_HIP(ctx, hipMemcpy(&lc.n_overflow, gp.n_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            lc.cam = *cam, lc.nx = nx, lc.ny = ny, lc.band = band, lc.count = scount, lc.id = prm->shard_id;
+            lc.valid = true;
+        }
         std::memset(stats, 0, sizeof(*stats));
         stats->n_paths = (uint64_t)npix * spp;
         stats->n_texture_fetches = h[0];
