@@ -231,6 +231,39 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def init_ranks(dist, backend, device, rank, world, emit, timeout_s=None):
+    """init_process_group with a limit of its own.  The rendezvous honours `timeout`; a communicator bring-up that wedges inside
+    the library (RCCL's eager init with device_id) does not, so a watchdog thread ends the rank: a JSON line with "error" from
+    rank 0 (stderr from the others) and a non-zero exit, instead of hanging until the driver's limit kills the run."""
+    import datetime
+    import threading
+    timeout_s = float(os.environ.get("RTOW_INIT_TIMEOUT_S", timeout_s or 180.0))
+    done = threading.Event()
+
+    def give_up(reason):
+        msg = (f"bench.py: rank {rank} of {world}: init_process_group({backend}) {reason} "
+               f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')}, MASTER_PORT={os.environ.get('MASTER_PORT')}, "
+               f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})")
+        sys.stderr.write(msg + "\n")
+        sys.stderr.flush()
+        if rank == 0:
+            emit({"error": msg, "value": None, "n_gpus": world, "rendered": False})
+        os._exit(3)
+
+    def watchdog():
+        if not done.wait(timeout_s + 15.0):
+            give_up(f"did not return within {timeout_s + 15.0:.0f} s")
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        kw = {"device_id": device} if device is not None else {}
+        dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
+    except Exception as e:  # noqa: BLE001 — whatever the rendezvous raised is the diagnostic
+        done.set()
+        give_up(f"failed: {type(e).__name__}: {e}")
+    done.set()
+
+
 def trace_roofline(trace_bytes, trace_s):
     achieved = trace_bytes / max(trace_s, 1e-12) / 1e9
     return round(achieved, 2), round(achieved / HBM_PEAK_GBPS, 5)
@@ -241,7 +274,7 @@ def build_record(*, config_id, cfg, nx, ny, spp, spp_total, scaling, max_depth, 
     """The JSON line of rank 0 from the aggregated measurements (pure: the CPU test of the multi-rank launch path builds the
     same line from a rehearsal's numbers).  per_rank: [(trace_seconds, trace_bytes_algorithmic)] of every rank over the timed
     steps; rank0: dict of rank 0's last RtStats fields + launch totals (None when nothing was rendered)."""
-    gather_name = "RCCL all_gather over xGMI" if backend == "nccl" else f"{backend} all_gather through host memory (rehearsal)"
+    gather_name = "RCCL gather to rank 0 over xGMI" if backend == "nccl" else f"{backend} gather to rank 0 through host memory (rehearsal)"
     per_gpu = f"{spp} spp per GPU ({spp_total} spp total)" if scaling == "weak" else f"{spp_total} spp"
     workload = (f"config {config_id}: {cfg['what']} {nx}x{ny}, {per_gpu}, max_depth {max_depth}, "
                 f"seed 95, counter RNG; rows sharded in bands of {band} over {world} GPU(s)"
@@ -261,7 +294,7 @@ def build_record(*, config_id, cfg, nx, ny, spp, spp_total, scaling, max_depth, 
         "steps": steps,
         "warmup": warmup,
         "ms_per_step": round(elapsed_max / max(steps, 1) * 1e3, 3) if rendered else None,
-        "gather_ms": gather_ms,  # all_gather + de-interleave per step, HIP events on the launch stream, max over ranks (null on 1 GPU)
+        "gather_ms": gather_ms,  # gather to rank 0 + its de-interleave per step, HIP events on the launch stream, max over ranks (null on 1 GPU)
         "higher_is_better": True,
         "scaling": scaling,
         "vs_baseline": None,
@@ -375,19 +408,21 @@ def main():
             torch.cuda.set_device(local_rank)
             dev = torch.device("cuda", local_rank)
         if world > 1:
-            if on_rccl:
-                dist.init_process_group(backend="nccl", device_id=dev)
-            else:
-                dist.init_process_group(backend="gloo")
+            init_ranks(dist, "nccl" if on_rccl else "gloo", dev if on_rccl else None, rank, world, emit)
             assert dist.get_world_size() == n_req
         cny, cnx = 64, 16
         rows = shard.shard_rows(cny, args.band, world, rank)
         local = torch.zeros((len(rows), cnx, 3), dtype=torch.float32, device=dev)
         local[:, :, 0] = torch.as_tensor(rows, dtype=torch.float32, device=dev)[:, None]  # every pixel carries its image row
         t0 = time.perf_counter()
-        full = shard.gather_framebuffer(local, cny, args.band) if world > 1 else local
+        full = shard.gather_framebuffer(local, cny, args.band, dst=0) if world > 1 else local
         gather_ms = round((time.perf_counter() - t0) * 1e3, 3) if world > 1 else None
-        ok = bool((full[:, 0, 0].cpu() == torch.arange(cny, dtype=torch.float32)).all())
+        # only rank 0 holds the frame (the others sent their bands and got None back)
+        ok = (full is None) if rank else bool((full[:, 0, 0].cpu() == torch.arange(cny, dtype=torch.float32)).all())
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
         if world > 1:
             dist.barrier()
         if rank == 0:
@@ -396,7 +431,7 @@ def main():
             rec = build_record(**common, backend=ran, elapsed_max=0.0, rays_total=0.0, gather_ms=gather_ms,
                                per_rank=[(0.0, 0)] * world, rank0=None, build_id=None, rendered=False)
             rec.update({"launcher_check": ok, "rccl_ranks": world if ran == "nccl" else 0, "backend": ran,
-                        "gather": "RCCL all_gather over xGMI" if ran == "nccl" else "gloo all_gather through host memory (rehearsal)"})
+                        "gather": "RCCL gather to rank 0 over xGMI" if ran == "nccl" else "gloo gather to rank 0 through host memory (rehearsal)"})
             emit(rec)
         if world > 1:
             dist.destroy_process_group()
@@ -407,10 +442,7 @@ def main():
     device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(device_index)
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend=backend)
+        init_ranks(dist, backend, torch.device("cuda", device_index) if backend == "nccl" else None, rank, world, emit)
         assert dist.get_world_size() == n_req, (dist.get_world_size(), n_req)
 
     import ray_tracing_in_one_weekend_amd as rt
@@ -452,13 +484,13 @@ def main():
             if world > 1 and backend == "nccl":
                 if k is not None:
                     ev[k][0].record()
-                full = shard.gather_framebuffer(local, w_ny, args.band)  # RCCL all_gather + de-interleave
+                full = shard.gather_framebuffer(local, w_ny, args.band, dst=0)  # RCCL gather; rank 0 de-interleaves
                 if k is not None:
                     ev[k][1].record()
             elif world > 1:
                 torch.cuda.current_stream().synchronize()
                 t0 = time.perf_counter()
-                full = shard.gather_framebuffer(local.cpu(), w_ny, args.band)
+                full = shard.gather_framebuffer(local.cpu(), w_ny, args.band, dst=0)
                 if k is not None:
                     ev[k] = (time.perf_counter() - t0) * 1e3
             else:

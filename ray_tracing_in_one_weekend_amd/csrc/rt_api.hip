@@ -60,15 +60,9 @@ struct RtCtx {
     GridParams grid{};
     size_t grid_lds = 0;
     uint32_t opt[RT_OPT__COUNT] = {}; // rt_debug_set_option: per context, every setting renders the same bits
-    // How many pixels of the last frame had more primary-ray candidates than a list holds, and which frame that was: the lists
-    // are a function of (scene, camera, frame geometry), so a following frame of the same view that had none does not even launch
-    // the depth-0 closest-hit kernel (its workgroups would return at once, but only after waiting for 66 KB of LDS each behind
-    // the other chain's shading waves).  Read with the counters of a render; a render without RtStats leaves it alone.
-    struct {
-        bool valid = false;
-        RtCamera cam{};
-        uint32_t nx = 0, ny = 0, band = 0, count = 0, id = 0, n_overflow = 0;
-    } list_cache;
+    // Page-locked word for the one host decision inside a frame: how many pixels have more primary-ray candidates than a list
+    // holds (k_primary_lists counts them; render_impl reads the count back 0.1 ms into the frame).
+    uint32_t* h_overflow = nullptr;
     // progressive preview (rt_set_progress): called from rt_render after every slice
     RtProgressFn progress_fn = nullptr;
     void* progress_user = nullptr;
@@ -113,7 +107,6 @@ void free_buf(DevBuf& b) {
 }
 
 void free_scene(RtCtx* ctx) {
-    ctx->list_cache.valid = false;
     for (void* p : ctx->scene_allocs) (void)hipFree(p);
     ctx->scene_allocs.clear();
     ctx->has_scene = false;
@@ -331,6 +324,7 @@ int rt_ctx_create(int device_id, RtCtx** out_ctx) {
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipHostMalloc((void**)&ctx->h_overflow, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     *out_ctx = ctx;
     return RT_OK;
 }
@@ -353,6 +347,7 @@ void rt_ctx_destroy(RtCtx* ctx) {
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
     delete ctx;
 }
 
@@ -909,7 +904,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     gp.seed_lo = (uint32_t)prm->seed, gp.seed_hi = (uint32_t)(prm->seed >> 32);
     gp.lists = nullptr;
     gp.n_overflow = nullptr;
-    bool same_view = false; // the candidate lists of this frame are the ones list_cache describes
+    bool no_overflow = false; // every pixel of this frame has a candidate list (read back from k_primary_lists below)
     {   // udiv_inv: reciprocals that keep the float quotient at or below the true one
         auto inv = [](uint32_t d) { return (float)((1.0 / (double)d) * (1.0 - 1.0 / 4194304.0)); };
         gp.inv_npix = inv(npix), gp.inv_nx = inv(nx), gp.inv_band = inv(band);
@@ -935,11 +930,19 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         uint32_t* n_overflow = (uint32_t*)((uint4*)ctx->lists.p + npix);
         gp.n_overflow = n_overflow;
         RT_HIP(ctx, hipMemsetAsync(n_overflow, 0, sizeof(uint4), st));
-        const auto& lc = ctx->list_cache;
-        same_view = lc.valid && std::memcmp(&lc.cam, cam, sizeof(RtCamera)) == 0 && lc.nx == nx && lc.ny == ny && lc.band == band &&
-                    lc.count == scount && lc.id == prm->shard_id;
         hipLaunchKernelGGL(k_primary_lists, dim3((npix + 255u) / 256u), dim3(256), (size_t)ctx->ds.n_entries * sizeof(float4) + 4u * RT_LIST_WAVE_CAP * 2u, st,
                            ctx->ds, gp, (uint4*)ctx->lists.p, n_overflow);
+        // The one host decision of a frame: with no overflowing list (every headline configuration) depth 0 of a sphere-only scene
+        // needs no closest-hit launch at all — k_shade<GEN> finds every hit from the lists.  An empty launch is not free: each of
+        // its workgroups waits for 66 KB of LDS behind the other chain's shading waves and holds its own chain's shading back
+        // (config 2: 1.6 ms of 47.6).  The count is there 0.1 ms into the frame; reading it costs one stream synchronisation while
+        // nothing else of the frame is enqueued yet, and the first frame of a view is as fast as any later one (the reference
+        // renders exactly one, main.rs:62-129).
+        if (!scene_is_general(ctx)) {
+            RT_HIP(ctx, hipMemcpyAsync(ctx->h_overflow, n_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            RT_HIP(ctx, hipStreamSynchronize(st));
+            no_overflow = *ctx->h_overflow == 0u;
+        }
     }
 
     uint32_t n_trace_launches = 0;
@@ -1004,7 +1007,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             ip.q0 = q0, ip.q1 = q1;
             const StepBuffers sb{qi, qo, qhit, cin, cout, rad, totals, gpd};
             // depth 0 of a sphere-only scene whose pixels all have a candidate list: k_shade<GEN> finds every closest hit itself
-            const bool no_primary_trace = gen && !rects && gp.lists != nullptr && same_view && ctx->list_cache.n_overflow == 0u;
+            const bool no_primary_trace = gen && !rects && gp.lists != nullptr && no_overflow;
             if (!no_primary_trace) launch_intersect(ctx, sg, use_bvh, gen, isect_grid_g, sb, ip);
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[3 * (size_t)depth + 1], st));
             // class sort from depth 1 on: primary rays are coherent already (measured: sorting depth 0 costs 8 %)
@@ -1012,7 +1015,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
                                  (prm->flags & RT_FLAG_RUSSIAN_ROULETTE) ? 1u : 0u, q0};
             launch_shade(ctx, sg, gen, !rects && gp.lists != nullptr, q1 - q0, sb, sp);
             if (td) RT_HIP(ctx, hipEventRecord(ctx->depth_events[3 * (size_t)depth + 2], st));
-            if (grp == 0u) n_trace_launches += 2;
+            if (grp == 0u) n_trace_launches += no_primary_trace ? 1u : 2u;
         }
         if (n_groups > 1u) {
             RT_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
@@ -1054,12 +1057,6 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         RT_HIP(ctx, hipStreamSynchronize(st));
         std::vector<unsigned long long> h((size_t)n_depths + 2);
         RT_HIP(ctx, hipMemcpy(h.data(), totals, totals_bytes, hipMemcpyDeviceToHost));
-        if (gp.n_overflow) {
-            auto& lc = ctx->list_cache;
-            RT_HIP(ctx, hipMemcpy(&lc.n_overflow, gp.n_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost));
-            lc.cam = *cam, lc.nx = nx, lc.ny = ny, lc.band = band, lc.count = scount, lc.id = prm->shard_id;
-            lc.valid = true;
-        }
         std::memset(stats, 0, sizeof(*stats));
         stats->n_paths = (uint64_t)npix * spp;
         stats->n_texture_fetches = h[0];
@@ -1365,6 +1362,18 @@ extern "C" int rt_debug_lane_stats(unsigned long long* out24, int reset) {
     if (reset) {
         const unsigned long long zero[RT_LANE_STAT_N] = {};
         if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_lane_stats), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+#ifdef RT_PROFILE_PHASES
+// Diagnostic builds only: the phase clocks of the class-sorting k_shade (rt_kernels.h), optionally reset after reading.
+extern "C" int rt_debug_phase_stats(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rt::g_phase_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long zero[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_phase_stats), zero, sizeof(zero)) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -955,6 +955,16 @@ struct ShadeParams {
     uint32_t q0;               // first shard of this launch (shard groups, rt_api.hip)
 };
 
+// Phase clocks (diagnostic builds only, -DRT_PROFILE_PHASES; scripts/gpu_phase_stats.py): s_memtime ticks a wave of the
+// class-sorting k_shade spends in  [0] the whole kernel  [1] the sort of a block (hit-record loads included)  [2] waiting for the
+// first segment's rays  [3] all-miss segments  [4] segments with hits;  [5] blocks  [6] all-miss segments  [7] segments with hits.
+#ifdef RT_PROFILE_PHASES
+__device__ unsigned long long g_phase_stats[16];
+#define RT_PHASE_CLOCK() __builtin_amdgcn_s_memtime()
+#else
+#define RT_PHASE_CLOCK() 0ull
+#endif
+
 // Shading half of the step: workgroup q owns shard q (reads it, appends survivors to shard q of the output queue
 // through an LDS counter, publishes the new count with a plain store).
 //
@@ -1053,11 +1063,18 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
     __syncthreads();
     uint32_t n_fetch = 0, n_bad = 0;
     const size_t qbase = (size_t)q * tp.cap;
+#ifdef RT_PROFILE_PHASES
+    unsigned long long ph[8] = {};
+    const unsigned long long ph_t0 = RT_PHASE_CLOCK();
+#endif
     // blocks of RT_SORT_N rays go round-robin to the four waves; a wave never waits for another one.  A short shard
     // (the deep bounces hold a few hundred rays per shard) is cut into four blocks so that every wave has work.
     const uint32_t bs = count >= 4u * RT_SORT_N ? RT_SORT_N : ((count + 255u) / 256u) * 64u;
     for (uint32_t base = w * bs; base < count; base += 4u * bs) {
         const uint32_t n_here = min(bs, count - base);
+#ifdef RT_PROFILE_PHASES
+        const unsigned long long ph_a = RT_PHASE_CLOCK();
+#endif
         if (sort) {
             // ---- wave-local counting sort of the block's hit records by shading class ---------------
             s_hist[lane] = 0u;
@@ -1070,19 +1087,55 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                 const uint32_t j = k * 64u + lane;
                 h[k] = j < n_here ? qh[qbase + base + j] : make_float2(0.0f, 0.0f);
             }
+#ifdef RT_HIST_BALLOT
+            // Rank of every record among those of its class, without LDS atomics: lane c keeps the running count of class c, and
+            // the records of one row are ranked class by class with a ballot (a row of sphere_scene holds 3-4 distinct classes,
+            // 61 % of its records in the one class "miss": 39 lanes adding to one LDS word was eight serialised atomics per block).
+            uint32_t cnt = 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < RT_SORT_N / 64u; ++k) {
+                const uint32_t j = k * 64u + lane;
+                const int hit = __float_as_int(h[k].y);
+                uint32_t key = 255u; // no record: matches no class
+#ifdef RT_DEBUG_QUEUE_BOUNDS
+                if (j < n_here && hit >= (int)(sc.n_prims + sc.n_media)) __builtin_trap();
+#endif
+                if (j < n_here) key = hit < 0 ? sc.key_miss : (uint32_t)cls[hit];
+                uint32_t rank = 0u;
+                unsigned long long todo = __ballot(j < n_here);
+                while (todo) {
+                    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__ffsll((long long)todo) - 1);
+                    const unsigned long long m = __ballot(key == kk);
+                    const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)kk);
+                    if (key == kk)
+                        rank = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (lane == kk) cnt += (uint32_t)__popcll(m);
+                    todo &= ~m;
+                }
+                kr[k] = key | (rank << 8);
+            }
+#else
 #pragma unroll
             for (uint32_t k = 0; k < RT_SORT_N / 64u; ++k) {
                 const uint32_t j = k * 64u + lane;
                 kr[k] = 0u;
                 if (j < n_here) {
                     const int hit = __float_as_int(h[k].y);
+#ifdef RT_DEBUG_QUEUE_BOUNDS // debug builds: a hit record names a world entry of the scene (a kernel that left qh unwritten would not)
+                    if (hit >= (int)(sc.n_prims + sc.n_media)) __builtin_trap();
+#endif
                     const uint32_t key = hit < 0 ? sc.key_miss : (uint32_t)cls[hit];
                     kr[k] = key | (atomicAdd(&s_hist[key], 1u) << 8);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#endif
             { // exclusive scan of the 64 class counts, one lane per class
+#ifdef RT_HIST_BALLOT
+                const uint32_t v = cnt;
+#else
                 const uint32_t v = s_hist[lane];
+#endif
                 uint32_t incl = v;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -1113,11 +1166,21 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                 uint32_t pj = j;
                 if (sort) h = s_rec[j], pj = s_pos[j];
                 else h = qh[qbase + base + j];
+#ifdef RT_WHATIF_COALESCED_GATHER // pricing only (wrong images): the rays of a segment from consecutive queue positions
+                const size_t r = qbase + base + j;
+#else
                 const size_t r = qbase + base + pj;
+#endif
                 ra = qin.a[RT_QSTRIDE * r], rb = qin.b[RT_QSTRIDE * r], rc = qin.c[r];
             }
         };
         fetch(0u, hA, raA, rbA, rcA);
+#ifdef RT_PROFILE_PHASES
+        const unsigned long long ph_b = RT_PHASE_CLOCK();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the diagnostic build exposes the first gather's latency as its own phase)
+        unsigned long long ph_c = RT_PHASE_CLOCK();
+        ph[1] += ph_b - ph_a, ph[2] += ph_c - ph_b, ph[5] += 1;
+#endif
         for (uint32_t seg = 0; seg < n_here; seg += 64u) {
             float2 hB = make_float2(0.0f, 0.0f), rcB = hB;
             float4 raB = make_float4(0.f, 0.f, 0.f, 0.f), rbB = raB;
@@ -1142,6 +1205,9 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                 }
                 prefetch();
                 hA = hB, raA = raB, rbA = rbB, rcA = rcB;
+#ifdef RT_PROFILE_PHASES
+                { const unsigned long long t = RT_PHASE_CLOCK(); ph[3] += t - ph_c, ph[6] += 1, ph_c = t; }
+#endif
                 continue;
             }
             bool alive = false;
@@ -1194,6 +1260,9 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                 if (!near_one(d)) { // main.rs:39 assert!: the reference panics; the path is dropped
                     ++n_bad;
                 } else {
+#ifdef RT_DEBUG_QUEUE_BOUNDS // debug builds: the record fetch of shade() is indexed by whatever the hit record holds
+                    if (__float_as_int(h.y) >= (int)(sc.n_prims + sc.n_media)) __builtin_trap();
+#endif
                     Rng rng{k0, k1, depth_counter_base(tp.depth)};
                     bo = shade<RECTS>(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch, prefetch);
                     if (bo.alive && tp.russian_roulette) { // main.rs:49-53
@@ -1232,8 +1301,17 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                 }
             }
             hA = hB, raA = raB, rbA = rbB, rcA = rcB;
+#ifdef RT_PROFILE_PHASES
+            { const unsigned long long t = RT_PHASE_CLOCK(); ph[4] += t - ph_c, ph[7] += 1, ph_c = t; }
+#endif
         }
     }
+#ifdef RT_PROFILE_PHASES
+    if (sort && lane == 0) {
+        ph[0] = RT_PHASE_CLOCK() - ph_t0;
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_stats[k], ph[k]);
+    }
+#endif
     __syncthreads();
     if (threadIdx.x == 0) out_counts[q] = *s_out;
     // rare-event counters: one atomic per wave, only when nonzero

@@ -1,8 +1,8 @@
 """Row-interleaved image sharding across ranks and the framebuffer gather.
 
 Image row j belongs to rank (j // band) % world.  Each rank renders its rows into a local
-[rows, nx, 3] f32 buffer in HBM; one all_gather (RCCL over xGMI when the backend is "nccl",
-gloo in the CPU tests) brings the bands together and `deinterleave` restores row order.  The
+[rows, nx, 3] f32 buffer in HBM; one gather to the rank that keeps the frame (or one all_gather when every rank wants it; RCCL over xGMI
+when the backend is "nccl", gloo in the CPU tests) brings the bands together and `deinterleave` restores row order.  The
 path has no other exchange step: scene and RNG keys are replicated, pixels are independent.
 """
 import numpy as np
@@ -41,15 +41,22 @@ def deinterleave(gathered, ny, band, world):
     return out
 
 
-def gather_framebuffer(local, ny, band, group=None):
-    """all_gather of the per-rank band buffers (torch.distributed; backend nccl == RCCL).
-    `local` is a torch tensor [rows_local, nx, 3]; returns the full [ny, nx, 3] image on every rank."""
+def gather_framebuffer(local, ny, band, group=None, dst=None):
+    """The framebuffer exchange of a frame (torch.distributed; backend nccl == RCCL over xGMI).
+    `local` is a torch tensor [rows_local, nx, 3].  dst=None: all_gather, the full [ny, nx, 3] image on every rank.
+    dst=r: gather to rank r only — the other ranks send their bands and return None; they neither receive the 8 x band
+    buffers nor de-interleave a frame nobody reads (config 3: 99.5 MB of index_copy_ per rank per frame)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     pad_rows = max_shard_rows(ny, band, world)
     padded = local.new_zeros((pad_rows,) + tuple(local.shape[1:]))
     padded[:local.shape[0]] = local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    return deinterleave(parts, ny, band, world)
+    if dst is None:
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        return deinterleave(parts, ny, band, world)
+    parts = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, parts, dst=dst, group=group)
+    return deinterleave(parts, ny, band, world) if rank == dst else None

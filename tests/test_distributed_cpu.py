@@ -36,6 +36,11 @@ def _worker(rank, world, port, band, out_dir):
     p = rt.make_params(nx, ny, 4, max_depth=12, shard_band=band, shard_count=world, shard_id=rank)
     local, _, st = orc.render(scene.flat_ptr, scene.camera, p, orc.options(n_threads=2))
     full = shard.gather_framebuffer(torch.from_numpy(local), ny, band)
+    # dst=0: only rank 0 receives and de-interleaves (what bench.py does every step); the other ranks get None
+    only0 = shard.gather_framebuffer(torch.from_numpy(local), ny, band, dst=0)
+    assert (only0 is None) == (rank != 0)
+    if rank == 0:
+        assert torch.equal(only0, full)
     rays = torch.tensor([st.n_rays], dtype=torch.int64)
     dist.all_reduce(rays)
     np.save(os.path.join(out_dir, f"full_{rank}.npy"), full.numpy())
@@ -98,6 +103,23 @@ def test_bench_launcher_spawns_the_ranks_itself(tmp_path):
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 
+def test_bench_rank_that_cannot_rendezvous_reports_and_exits(tmp_path):
+    """A rank whose peers never arrive must not hang to the driver's limit: init_ranks gives up after its own timeout, rank 0
+    prints a JSON line with "error" and the process exits non-zero."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RTOW_DIST_BACKEND="gloo", RTOW_INIT_TIMEOUT_S="5", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-check"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stderr[-2000:]
+    out = json.loads(lines[-1])
+    assert "init_process_group(gloo)" in out["error"] and out["value"] is None and out["n_gpus"] == 2
+
+
 def test_bench_record_of_a_two_rank_run():
     """bench.build_record on the numbers of a 2-rank run: whole-job rays over the slowest rank's time, every rank's own
     trace-step HBM fraction, the gather time; and a one-GPU default run is config 2."""
@@ -110,4 +132,4 @@ def test_bench_record_of_a_two_rank_run():
                              per_rank=[(0.2, 4e11), (0.25, 4e11)], rank0=r0, build_id="0" * 16)
     assert rec["value"] == 8000.0 and rec["ms_per_step"] == 250.0 and rec["gather_ms"] == 0.4 and rec["rccl_ranks"] == 2
     assert rec["roofline"]["frac"] == 0.25 and [q["frac"] for q in rec["roofline"]["per_rank"]] == [0.25, 0.2]
-    assert "RCCL all_gather" in rec["config"]["workload"] and rec["config"]["paths_per_step"] == 3840 * 2160 * 1024
+    assert "RCCL gather to rank 0" in rec["config"]["workload"] and rec["config"]["paths_per_step"] == 3840 * 2160 * 1024
