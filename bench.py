@@ -213,6 +213,62 @@ def in_library_check(rt, scene, renderer, frame, n_dev, timeout_s=150.0):
     return res
 
 
+def first_frame_child(cfg, nx, ny, spp, max_depth):
+    """What the reference's own timer covers (utils.rs:15-18 around main.rs:70-126: scene build + render, ONE frame per process),
+    measured in a process of its own: HIP runtime start, rt_ctx_create, host-side scene build (image decode included),
+    rt_scene_upload and the first rt_render with its buffer allocations, wall clock; a second frame for comparison; and what the
+    process allocated on the device.  No torch here: the child is the library and its ctypes wrapper, nothing else.  Prints one
+    JSON object."""
+    import ctypes
+    t0 = time.perf_counter()
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, tot = ctypes.c_size_t(), ctypes.c_size_t()
+        return f.value if hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(tot)) == 0 else None
+    free0 = free_bytes()
+    import ray_tracing_in_one_weekend_amd as rt
+    t_rt = time.perf_counter()
+    renderer = rt.Renderer(0)
+    t_ctx = time.perf_counter()
+    rt.register_default_images()
+    scene = rt.Scene.build(cfg["scene"], nx / ny)
+    t_scene = time.perf_counter()
+    renderer.upload(scene)
+    t_up = time.perf_counter()
+    params = rt.make_params(nx, ny, spp, max_depth=max_depth, seed=95)
+    _, _, st1 = renderer.render(scene.camera, params, want_rgb8=True, pinned=True)
+    t_f1 = time.perf_counter()
+    free1 = free_bytes()
+    _, _, st2 = renderer.render(scene.camera, params, want_rgb8=True, pinned=True)
+    t_f2 = time.perf_counter()
+    ms = lambda a, b: round((b - a) * 1e3, 2)
+    print(json.dumps({
+        "first_frame_ms": ms(t_rt, t_f1),  # rt_ctx_create + scene build + rt_scene_upload + first rt_render (f32 + RGB8 to the host)
+        "parts_ms": {"hip_runtime_and_import": ms(t0, t_rt), "rt_ctx_create": ms(t_rt, t_ctx), "scene_build_host": ms(t_ctx, t_scene),
+                     "rt_scene_upload": ms(t_scene, t_up), "first_rt_render": ms(t_up, t_f1), "second_rt_render": ms(t_f1, t_f2)},
+        "first_render_device_ms": round(st1.seconds_device * 1e3, 3), "second_render_device_ms": round(st2.seconds_device * 1e3, 3),
+        "first_render_trace_launches": int(st1.n_trace_launches), "second_render_trace_launches": int(st2.n_trace_launches),
+        "alloc_bytes": (free0 - free1) if free0 is not None and free1 is not None else None,
+        "note": "a process of its own (no torch): wall clock from before rt_ctx_create to the first frame in host memory; "
+                "alloc_bytes = device memory this process holds after its first frame (hipMemGetInfo before / after)"}))
+    renderer.close()
+
+
+def first_frame(config_id, nx, ny, spp, max_depth, timeout_s=240.0):
+    """Runs first_frame_child in a fresh process and returns its record (or {"error": ...})."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--first-frame-child", "--config", str(config_id), "--nx", str(nx), "--ny", str(ny),
+           "--spp", str(spp), "--max-depth", str(max_depth)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"child exited {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+        return json.loads(lines[-1])
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -355,11 +411,16 @@ def main():
     ap.add_argument("--in-library", action="store_true",
                     help="after the timed region, rank 0 also renders through rt_multi_render (one process, all --gpus devices, the RCCL "
                          "gather inside the library) and reports bit-identity with rt_render; always on when --gpus > 1")
+    ap.add_argument("--first-frame-child", action="store_true", help=argparse.SUPPRESS)  # (the fresh process of first_frame())
     ap.add_argument("--launcher-check", action="store_true",
                     help="rendezvous, world-size assertion and one framebuffer gather of a synthetic band buffer; no rendering "
                          "(the CPU test of the multi-rank launch path: RTOW_DIST_BACKEND=gloo, no GPU needed)")
     args = ap.parse_args()
 
+    if args.first_frame_child:
+        cfg = CONFIGS[args.config or 2]
+        first_frame_child(cfg, args.nx or cfg["nx"], args.ny or cfg["ny"], args.spp or cfg["spp"], args.max_depth)
+        return
     n_req = max(args.gpus, 1)
     if n_req > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(n_req))
@@ -572,6 +633,12 @@ def main():
                 _, _, sth = renderer.render(scene.camera, params, want_rgb8=True, pinned=True)
                 host_rays += sth.n_rays
             out["value_host_inclusive"] = round(host_rays / (time.perf_counter() - th0) / 1e6, 3)
+        if world == 1 and not args.timed_only:
+            # every number above is a warm, steady-state frame; the reference renders ONE frame per process (main.rs:62-129)
+            ff = first_frame(config_id, nx, ny, spp_total, args.max_depth)
+            out["first_frame"] = ff
+            out["first_frame_ms"] = ff.get("first_frame_ms")
+            out["alloc_bytes"] = ff.get("alloc_bytes")
         if args.in_library or world > 1:
             out["in_library"] = in_library
         if world == 1 and not args.no_cpu_baseline and not args.timed_only:

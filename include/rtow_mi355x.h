@@ -357,9 +357,13 @@ int rt_deinterleave_bands(RtCtx* ctx, const void* d_gathered, uint32_t nx, uint3
                           void* d_out_rgb_f32, void* d_out_rgb8, void* stream);
 
 /* -- debug / tuning options (test hooks) ---------------------------------------------------------------------------
- * Per context (not per process: the library reads no environment variable); EVERY setting renders the same bits — the
+ * Per context (not per process: the library reads no environment variable); every setting renders the same image — the
  * options select between equivalent search structures, placements and orders so that tests can hold them against each
- * other, and so that measurements can vary one thing.  0 is the library's own choice for every option.  Options marked
+ * other, and so that measurements can vary one thing.  Same BITS with one stated exception: the closest-hit searches
+ * (list walk, tree, grid, candidate lists) agree on every ray except those for which fp32 Sphere::hit (hitable.rs:75-91)
+ * reports a root although the ray misses the sphere in exact arithmetic (cancellation at grazing incidence); a box or cell
+ * test may cull such a false positive, the list walk cannot.  Measured: at most 8 of the 1.35e9 rays of config 2, each
+ * proven a false positive in float64 by the tests.  Which of them the reference's own binary BvhNode would cull is unpinned.  0 is the library's own choice for every option.  Options marked
  * (upload) take effect at the next rt_scene_upload, the others at the next render. */
 enum RtDebugOption {
     RT_OPT_TREE_PLACEMENT = 0,        /* (upload) 1: the BVH is read through L2 even when it would fit LDS */

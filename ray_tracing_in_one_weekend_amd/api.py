@@ -268,11 +268,11 @@ class Renderer:
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         key = np.dtype(dtype).char
         if not hasattr(self, "_pin"):
-            self._pin = {}
+            self._pin, self._pin_retired = {}, []
         ptr, size = self._pin.get(key, (None, 0))
         if size < n:
-            if ptr:
-                self._lib.rt_host_free(ptr)
+            if ptr:  # arrays handed out earlier are views of it: an outgrown buffer lives until close()
+                self._pin_retired.append(ptr)
             ptr = self._lib.rt_host_alloc(max(n, 1))
             if not ptr:
                 raise RtError("rt_host_alloc failed")
@@ -282,7 +282,8 @@ class Renderer:
 
     def render(self, camera, params, want_rgb8=False, pinned=False):
         """Returns (f32 image [rows, nx, 3] (row 0 = bottom), rgb8 or None, RtStats).  pinned=True: the arrays are views of
-        this Renderer's page-locked staging buffers (valid until the next pinned render or close())."""
+        this Renderer's page-locked staging buffers: overwritten by the next pinned render, and their memory is FREED by close() —
+        copy what must outlive the Renderer."""
         rows = self.shard_rows(params)
         if pinned:
             img = self._pinned((rows, params.nx, 3), np.float32)
@@ -367,10 +368,10 @@ class Renderer:
         if self._ctx:
             self._lib.rt_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
-        for ptr, _ in getattr(self, "_pin", {}).values():
+        for ptr in [q for q, _ in getattr(self, "_pin", {}).values()] + getattr(self, "_pin_retired", []):
             if ptr:
-                self._lib.rt_host_free(ptr)
-        self._pin = {}
+                self._lib.rt_host_free(ptr)  # (invalidates every array a pinned render() returned)
+        self._pin, self._pin_retired = {}, []
 
     def __del__(self):
         try:

@@ -35,6 +35,9 @@ struct RtCtx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // second shard group of a slice (render_impl)
+    std::vector<hipStream_t> parked_streams;  // streams that turned out to share a hardware queue with the first chain's (ensure_concurrent_chains)
+    hipStream_t paired_with = nullptr;        // the launch stream stream2 was last checked against
+    bool chains_concurrent = true;            // what that check found (false: no stream of this process ran beside the launch stream)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     // scene
@@ -138,6 +141,67 @@ bool class_is_light(uint32_t cls, uint32_t sky_type) {
     return tt == RT_TEX_CONSTANT && ty <= RT_MAT_ISOTROPIC;
 }
 
+
+// ---- two chains need two hardware queues ----------------------------------------------------------------------
+// HIP multiplexes the streams of a process onto a small pool of hardware queues (4 by default), and two streams that share one
+// run their kernels one after the other: the two chains of a slice then gain nothing from each other (config 2: 54.7 ms instead
+// of 48.5; which context of a process draws the shared queue depends on how many streams exist — the "second-listed context
+// reads 12 % high" of round 4's A/B runs, profiles/round5/ab_same_binary_four_contexts.txt).  Before the first frame on a
+// launch stream, two single-wave spin kernels tell whether `stream2` runs beside it; if not, stream2 is parked (kept alive, so
+// the slot stays taken) and a fresh stream tried, a few times.  Speed only: results never depend on it.
+__global__ void k_spin(unsigned long long ticks, unsigned long long* sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t = t0;
+    for (uint32_t n = 0; n < (1u << 20) && t - t0 < ticks; ++n) { // bounded: every wave leaves
+        __builtin_amdgcn_s_sleep(16);
+        t = __builtin_amdgcn_s_memtime();
+    }
+    if (sink) *sink = t - t0;
+}
+int ensure_concurrent_chains(RtCtx* ctx, hipStream_t st) {
+    if (ctx->paired_with == st) return RT_OK;
+    const unsigned long long ticks = 150000ull; // ~60 us
+    hipEvent_t e0 = nullptr, e1 = nullptr; // (its own pair: ev_begin / ev_end bracket the frame this runs inside)
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    auto timed = [&](bool both, float& ms) -> int {
+        RT_HIP(ctx, hipEventRecord(e0, st));
+        if (both) {
+            RT_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, ctx->stream2, ticks, (unsigned long long*)nullptr);
+        }
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, ticks, (unsigned long long*)nullptr);
+        if (both) {
+            RT_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+            RT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+        }
+        RT_HIP(ctx, hipEventRecord(e1, st));
+        RT_HIP(ctx, hipStreamSynchronize(st));
+        RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+        return RT_OK;
+    };
+    int rc;
+    float one = 0.f, both = 0.f;
+    if (!(rc = timed(false, one)) && !(rc = timed(false, one))) { // (the first launch of a kernel pays its load)
+        for (int attempt = 0;; ++attempt) {
+            if ((rc = timed(true, both))) break;
+            ctx->chains_concurrent = both < 1.6f * one;
+            if (ctx->chains_concurrent || attempt == 6) break;
+            hipStream_t fresh = nullptr;
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            ctx->parked_streams.push_back(ctx->stream2);
+            ctx->stream2 = fresh;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!rc) ctx->paired_with = st;
+    return rc;
+}
 
 // ---- the two trace-step launches (render_impl and the production-kernel test hook share them) ----------------
 struct StepBuffers {
@@ -346,6 +410,7 @@ void rt_ctx_destroy(RtCtx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (auto sp : ctx->parked_streams) (void)hipStreamDestroy(sp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
     delete ctx;
@@ -972,6 +1037,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t chains_opt = ctx->opt[RT_OPT_CHAINS];
     const bool one_chain = chains_opt ? chains_opt == 1u : (ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0 || (use_bvh && !ctx->bvh_in_lds));
     const uint32_t n_groups = (nq >= 2u * RT_ISECT_MAX_SHARDS && !time_depths && !one_chain) ? 2u : 1u;
+    if (n_groups > 1u && (rc = ensure_concurrent_chains(ctx, st))) return rc;
     const uint32_t shards_per_wg = (nq + isect_grid - 1u) / isect_grid;
     // selects the "general scene" kernel instantiations (rectangles and Translate / RotateY wrappers)
     const bool rects = scene_is_general(ctx);

@@ -9,8 +9,10 @@
 // 3.9 cell steps + 2.8 sphere tests in cells + 4 always-tested large spheres (scripts/whatif_grid_sim.py, the CPU what-if
 // that preceded this file).  The result is the SAME: every sphere whose exact Sphere::hit root (hitable.rs:75-91) could win
 // is tested with the same sphere_root and the same order-independent winner rule as the tree and the list walk
-// (hitable.rs:117-132: smallest accepted root, ties to the later sphere), so hit records are bit-identical
-// (tests: grid == tree == list walk on adversarial rays and on whole frames).
+// (hitable.rs:117-132: smallest accepted root, ties to the later sphere), so hit records are bit-identical — except where
+// fp32 Sphere::hit reports a root for a ray that misses the sphere in exact arithmetic: a cell or box test may cull such a false
+// positive, the list walk cannot (at most 8 of the 1.35e9 rays of config 2; each proven in float64 by the tests: grid == tree ==
+// list walk on adversarial rays and on whole frames).
 //
 // Structure.  Spheres whose padded box would cover more than RT_GRID_BIG_CELLS cells ("large": the r = 1000 ground of
 // sphere_scene, its three r = 1 spheres) are tested for every ray when the lane takes the ray (all lanes of a refill
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
                 if (!(mo <= G.max_coord)) { // far away (or NaN): every sphere, no walk
                     cnt = G.all_rec & RT_GRID_CNT_MASK, off = G.all_rec >> RT_GRID_CNT_BITS;
                     texit = -RT_FLT_MAX;
+                    tmx = tmy = tmz = INFINITY; // (the walk step behind the list then finishes the ray whatever tbest holds)
                 } else if (!(tn <= tf) || !(tn < tbest)) { // misses the grid, or reaches it behind the best large sphere
                     qh[pos] = make_float2(tbest, __int_as_float(hit));
                     has = false;
@@ -362,6 +365,7 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
             } else if (--budget == 0u) { // cannot happen for a DDA; keeps the loop finite whatever the arithmetic did
                 cnt = G.all_rec & RT_GRID_CNT_MASK, off = G.all_rec >> RT_GRID_CNT_BITS;
                 texit = -RT_FLT_MAX;
+                tmx = tmy = tmz = INFINITY; // tnext = inf is never < min(tbest, texit): the lane finishes right behind the list
             } else {
                 const bool ax = tmx <= tnext, ay = !ax && tmy <= tnext, az = !ax && !ay;
                 cell += ax ? sx : (ay ? sy : sz);

@@ -525,6 +525,10 @@ struct BvhLds {
     uint32_t n_spheres;
     GenTables gt;          // wrapper / medium tables of general scenes (HBM, or LDS with GLDS)
     unsigned short* stack; // this lane's column: stack[level * BLOCK]
+    // QT (stage_qtree): the tree in 58 B per node, in LDS, walked without a stack (bvh_step_q)
+    const uint4* qp[3];
+    const uint2* qid;
+    const unsigned short* qpar;
 };
 
 // LDS_NODES = false: the tree and the primitive geometry stay in HBM (scenes whose tree does not fit the
@@ -728,6 +732,141 @@ __device__ __forceinline__ bool media_step(const BvhLds& L, V3 o, V3 d, const Me
     }
     return pend == 0u;
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// QT: the 4-wide tree of a general scene in LDS at 58 B per node, walked without a stack (round 5).
+//
+// final_scene's tree (1 150 nodes x 112 B) does not fit LDS beside a second 1 024-thread workgroup, and neither do the per-lane
+// stacks (u16 x 3 levels per tree level x 1 024 lanes = 40 KB): until round 4 such a tree was read through L2, seven dependent 16 B
+// gathers per node step.  Here the child planes are halves rounded OUTWARD (a box only ever grows: culling stays conservative, the
+// exact leaf tests decide as before), the child ids are u16, and what a lane has still to visit is a 64-bit TRAIL instead of a
+// stack: four bits per tree level — the inner children of that level's node that were hit but not entered — under a sentinel bit.
+// A node step tests the four child boxes against [0, tbest] exactly like bvh_step, tests the hit leaves, enters the nearest hit
+// inner child and leaves the other hit ones in the trail; a lane that has nothing to enter climbs (u16 parent links) to the
+// first level whose nibble is not empty and enters the lowest child noted there.  The visiting order is the stack version's
+// up to the order among siblings, and the winner rule does not depend on it.  (A sibling is not re-tested against the tbest
+// of the moment it is finally entered — the stack version does not do that either.)
+#define RT_QT_EMPTY 0xFFFFu
+#define RT_QT_LEAF 0x8000u
+#define RT_QT_MAX_DEPTH 15u // 4 bits per level + the sentinel in 64 bits
+__host__ __device__ inline size_t qtree_lds_bytes(uint32_t n_nodes) { return (((size_t)n_nodes * 58u + 15u) & ~(size_t)15u) + 16u; }
+template <int BLOCK>
+__device__ __forceinline__ BvhLds stage_qtree(const DevScene& sc, char* smem) {
+    const uint32_t n = sc.n_bvh4_nodes;
+    BvhLds L;
+    uint4* pl = reinterpret_cast<uint4*>(smem);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (uint32_t i = threadIdx.x; i < n; i += BLOCK) pl[(size_t)a * n + i] = sc.q_plane[a][i];
+        L.qp[a] = pl + (size_t)a * n;
+    }
+    uint2* ids = reinterpret_cast<uint2*>(pl + 3u * (size_t)n);
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) ids[i] = sc.q_ids[i];
+    unsigned short* par = reinterpret_cast<unsigned short*>(ids + n);
+    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) par[i] = sc.q_parent[i];
+    L.qid = ids, L.qpar = par;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) L.pl[a] = sc.bvh4_p[a];
+    L.id = sc.bvh4_id;
+    L.geo = sc.prim_geo; // leaf geometry stays in HBM / L2
+    L.n_spheres = sc.n_spheres;
+    L.gt = tables_of(sc);
+    L.stack = nullptr;
+    return L;
+}
+__device__ __forceinline__ float4 halves_lo(uint4 v) { // the four halves of (x, y) as floats
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y);
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+__device__ __forceinline__ float4 halves_hi(uint4 v) { // the four halves of (z, w)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_bit_cast(h2, v.z), b = __builtin_bit_cast(h2, v.w);
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+// One traversal step of one lane on the quantised tree; `trail` as described above (1 = at the root, nothing noted).
+// Returns true when the traversal of this ray has finished.
+template <bool RECTS>
+__device__ __forceinline__ bool bvh_step_q(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float nox, float noy, float noz,
+                                           float eps, bool exact, float a, uint32_t& pend, int& cur, unsigned long long& trail,
+                                           float& tbest, int& hit) {
+    {
+        RT_LANE_STAT(2, true);
+        const uint4 qx = L.qp[0][cur], qy = L.qp[1][cur], qz = L.qp[2][cur];
+        const uint2 qi = L.qid[cur];
+        const float4 mnx = halves_lo(qx), mxx = halves_hi(qx), mny = halves_lo(qy), mxy = halves_hi(qy), mnz = halves_lo(qz), mxz = halves_hi(qz);
+        const uint32_t idv[4] = {qi.x & 0xFFFFu, qi.x >> 16, qi.y & 0xFFFFu, qi.y >> 16};
+        const float tb = __builtin_fmaf(tbest, 1.000004f, eps);
+        uint32_t lq0 = 0u, lq1 = 0u; // the hit leaf children of this node, entry id + 1 in 16 bits each
+        float best_t = RT_FLT_MAX;
+        uint32_t best = RT_QT_EMPTY, best_slot = 0u, others = 0u;
+#define RT_CHILD_Q(K, S)                                                                                      \
+    {                                                                                                         \
+        const uint32_t idk = idv[S];                                                                          \
+        const float x0 = RT_T(mnx.K, ix, nox, o.x), x1 = RT_T(mxx.K, ix, nox, o.x);                           \
+        const float y0 = RT_T(mny.K, iy, noy, o.y), y1 = RT_T(mxy.K, iy, noy, o.y);                           \
+        const float z0 = RT_T(mnz.K, iz, noz, o.z), z1 = RT_T(mxz.K, iz, noz, o.z);                           \
+        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));              \
+        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));                           \
+        if (tn <= fminf(__builtin_fmaf(tf, 1.000004f, eps), tb) && idk != RT_QT_EMPTY) {                      \
+            if (idk & RT_QT_LEAF) { /* a leaf: queued for the leaf loop behind the four box tests */          \
+                lq1 = (lq1 << 16) | (lq0 >> 16);                                                               \
+                lq0 = (lq0 << 16) | ((idk & 0x7FFFu) + 1u);                                                    \
+            } else if (tn < best_t) { /* new nearest: the previous nearest (if any) is noted in the trail */  \
+                if (best != RT_QT_EMPTY) others |= 1u << best_slot;                                            \
+                best_t = tn, best = idk, best_slot = S;                                                        \
+            } else {                                                                                          \
+                others |= 1u << S;                                                                             \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+        if (!exact) {
+#define RT_T(B, INV, NO, O) __builtin_fmaf(B, INV, NO)
+            RT_CHILD_Q(x, 0)
+            RT_CHILD_Q(y, 1)
+            RT_CHILD_Q(z, 2)
+            RT_CHILD_Q(w, 3)
+#undef RT_T
+        } else { // rays almost parallel to an axis plane (see k_intersect): plane distances without cancellation
+#define RT_T(B, INV, NO, O) (((B) - (O)) * (INV))
+            RT_CHILD_Q(x, 0)
+            RT_CHILD_Q(y, 1)
+            RT_CHILD_Q(z, 2)
+            RT_CHILD_Q(w, 3)
+#undef RT_T
+        }
+#undef RT_CHILD_Q
+        ChainCache cc;
+        cc.xf = RT_NO_XFORM_DEV;
+        while (lq0 != 0u) {
+            RT_LANE_STAT(4, true);
+            const int s = (int)(lq0 & 0xFFFFu) - 1;
+            lq0 = (lq0 >> 16) | (lq1 << 16);
+            lq1 >>= 16;
+            leaf_test<RECTS>(L, s, o, d, a, pend, tbest, hit, RECTS ? &cc : nullptr);
+        }
+        if (best != RT_QT_EMPTY) {
+            trail = (trail << 4) | others;
+            cur = (int)best;
+            return false;
+        }
+    }
+    // nothing to enter below this node: climb to the first level that has a child noted, enter the lowest one
+    while (trail != 1ull) { // (at most RT_QT_MAX_DEPTH trips)
+        const uint32_t m = (uint32_t)trail & 15u;
+        cur = (int)L.qpar[cur];
+        if (m) {
+            const uint32_t s = (uint32_t)__ffs((int)m) - 1u;
+            trail = (trail & ~15ull) | (m & (m - 1u));
+            const uint2 qi = L.qid[cur];
+            const uint32_t w2 = s < 2u ? qi.x : qi.y;
+            cur = (int)((s & 1u) ? w2 >> 16 : w2 & 0xFFFFu); // (its own node step pushes its level)
+            return false;
+        }
+        trail >>= 4;
+    }
+    return true;
+}
+
 struct IntersectParams {
     uint32_t nq, cap;
     int depth;
@@ -743,7 +882,7 @@ struct IntersectParams {
 // 1024-thread workgroups (8 waves per SIMD) share a CU and hide each other's dependent node fetches
 // — measured +15 % on cornell_box and +20 % on final_scene against 7 waves = one workgroup.
 // GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
-template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES, bool GLDS>
+template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES, bool GLDS, bool QT = false>
 __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float4* __restrict__ qa,
                                                      const float4* __restrict__ qb,
                                                      float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
@@ -763,9 +902,10 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
     const uint32_t total = pre[RT_ISECT_MAX_SHARDS];
     if (total == 0) return; // block-uniform
     if (GEN && !RECTS && gpd->lists && *gpd->n_overflow == 0u) return; // every pixel has a list: k_shade<GEN> finds all closest hits of depth 0
-    BvhLds L = stage_bvh<BLOCK, LDS_NODES>(sc, smem);
-    if (GLDS) L.gt = stage_general<BLOCK>(sc, smem + bvh_lds_bytes(sc, BLOCK, LDS_NODES));
-    uint32_t* s_work = reinterpret_cast<uint32_t*>(smem + bvh_lds_bytes(sc, BLOCK, LDS_NODES) - 16u);
+    const size_t tree_bytes = QT ? qtree_lds_bytes(sc.n_bvh4_nodes) : bvh_lds_bytes(sc, BLOCK, LDS_NODES);
+    BvhLds L = QT ? stage_qtree<BLOCK>(sc, smem) : stage_bvh<BLOCK, LDS_NODES>(sc, smem);
+    if (GLDS) L.gt = stage_general<BLOCK>(sc, smem + tree_bytes);
+    uint32_t* s_work = reinterpret_cast<uint32_t*>(smem + tree_bytes - 16u);
     if (threadIdx.x == 0) *s_work = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -778,6 +918,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
     V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
     float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, eps = 0.f, a = 1.0f, tbest = RT_FLT_MAX;
     int hit = -1, cur = 0, sp = 0;
+    unsigned long long trail = 1ull; // QT: what this lane has still to visit (bvh_step_q)
     size_t pos = 0;
     MediumCtx mc{0u, 0u, depth_counter_base(ip.depth)};
     // Sorted slab planes for sphere-only scenes with the tree in LDS.  General scenes: the six extra registers spill in the
@@ -848,6 +989,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 hit = -1;
                 cur = 0;
                 sp = 0;
+                trail = 1ull;
                 has = !no_geometry;
                 trav = true;
                 pend = 0u;
@@ -887,7 +1029,8 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 continue;
             }
         }
-        if (has && trav && bvh_step<BLOCK, RECTS, SORTED>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit, &planes)) {
+        if (has && trav && (QT ? bvh_step_q<RECTS>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, trail, tbest, hit)
+                               : bvh_step<BLOCK, RECTS, SORTED>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit, &planes))) {
             if (RECTS && pend) {
                 trav = false;
             } else {
@@ -957,7 +1100,8 @@ struct ShadeParams {
 
 // Phase clocks (diagnostic builds only, -DRT_PROFILE_PHASES; scripts/gpu_phase_stats.py): s_memtime ticks a wave of the
 // class-sorting k_shade spends in  [0] the whole kernel  [1] the sort of a block (hit-record loads included)  [2] waiting for the
-// first segment's rays  [3] all-miss segments  [4] segments with hits;  [5] blocks  [6] all-miss segments  [7] segments with hits.
+// first segment's rays  [3] all-miss segments  [4] segments with hits;  [5] blocks  [6] all-miss segments  [7] segments with hits
+// [8] (in front of [1]) waiting for the stores of the block before  [9] (inside [1]) the eight hit-record loads, issue to arrival.
 #ifdef RT_PROFILE_PHASES
 __device__ unsigned long long g_phase_stats[16];
 #define RT_PHASE_CLOCK() __builtin_amdgcn_s_memtime()
@@ -1064,7 +1208,7 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
     uint32_t n_fetch = 0, n_bad = 0;
     const size_t qbase = (size_t)q * tp.cap;
 #ifdef RT_PROFILE_PHASES
-    unsigned long long ph[8] = {};
+    unsigned long long ph[10] = {};
     const unsigned long long ph_t0 = RT_PHASE_CLOCK();
 #endif
     // blocks of RT_SORT_N rays go round-robin to the four waves; a wave never waits for another one.  A short shard
@@ -1073,7 +1217,10 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
     for (uint32_t base = w * bs; base < count; base += 4u * bs) {
         const uint32_t n_here = min(bs, count - base);
 #ifdef RT_PROFILE_PHASES
+        const unsigned long long ph_a0 = RT_PHASE_CLOCK();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic: the stores of the block before, on their own)
         const unsigned long long ph_a = RT_PHASE_CLOCK();
+        ph[8] += ph_a - ph_a0;
 #endif
         if (sort) {
             // ---- wave-local counting sort of the block's hit records by shading class ---------------
@@ -1082,39 +1229,20 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                                                                    // keeps the compiler from moving them across
             float2 h[RT_SORT_N / 64u];
             uint32_t kr[RT_SORT_N / 64u]; // key | rank << 8
+            // s_waitcnt vmcnt(0) as the BUILTIN, so that the compiler's own wait insertion knows that nothing is in flight: without
+            // it the eight loads below are cut in two groups by a wait (their registers were prefetch destinations of the block
+            // before), two memory round trips of ~25 000 cycles instead of one.  What is still outstanding here are the stores of
+            // the block before, and they have long drained (63 cycles on average: profiles/round5/phases_k_shade.txt).
+            __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
             for (uint32_t k = 0; k < RT_SORT_N / 64u; ++k) {
                 const uint32_t j = k * 64u + lane;
                 h[k] = j < n_here ? qh[qbase + base + j] : make_float2(0.0f, 0.0f);
             }
-#ifdef RT_HIST_BALLOT
-            // Rank of every record among those of its class, without LDS atomics: lane c keeps the running count of class c, and
-            // the records of one row are ranked class by class with a ballot (a row of sphere_scene holds 3-4 distinct classes,
-            // 61 % of its records in the one class "miss": 39 lanes adding to one LDS word was eight serialised atomics per block).
-            uint32_t cnt = 0u;
-#pragma unroll
-            for (uint32_t k = 0; k < RT_SORT_N / 64u; ++k) {
-                const uint32_t j = k * 64u + lane;
-                const int hit = __float_as_int(h[k].y);
-                uint32_t key = 255u; // no record: matches no class
-#ifdef RT_DEBUG_QUEUE_BOUNDS
-                if (j < n_here && hit >= (int)(sc.n_prims + sc.n_media)) __builtin_trap();
+#ifdef RT_PROFILE_PHASES
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic: the eight hit-record loads, on their own)
+            ph[9] += RT_PHASE_CLOCK() - ph_a;
 #endif
-                if (j < n_here) key = hit < 0 ? sc.key_miss : (uint32_t)cls[hit];
-                uint32_t rank = 0u;
-                unsigned long long todo = __ballot(j < n_here);
-                while (todo) {
-                    const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)__ffsll((long long)todo) - 1);
-                    const unsigned long long m = __ballot(key == kk);
-                    const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)kk);
-                    if (key == kk)
-                        rank = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (lane == kk) cnt += (uint32_t)__popcll(m);
-                    todo &= ~m;
-                }
-                kr[k] = key | (rank << 8);
-            }
-#else
 #pragma unroll
             for (uint32_t k = 0; k < RT_SORT_N / 64u; ++k) {
                 const uint32_t j = k * 64u + lane;
@@ -1129,13 +1257,8 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#endif
             { // exclusive scan of the 64 class counts, one lane per class
-#ifdef RT_HIST_BALLOT
-                const uint32_t v = cnt;
-#else
                 const uint32_t v = s_hist[lane];
-#endif
                 uint32_t incl = v;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
@@ -1166,11 +1289,7 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                 uint32_t pj = j;
                 if (sort) h = s_rec[j], pj = s_pos[j];
                 else h = qh[qbase + base + j];
-#ifdef RT_WHATIF_COALESCED_GATHER // pricing only (wrong images): the rays of a segment from consecutive queue positions
-                const size_t r = qbase + base + j;
-#else
                 const size_t r = qbase + base + pj;
-#endif
                 ra = qin.a[RT_QSTRIDE * r], rb = qin.b[RT_QSTRIDE * r], rc = qin.c[r];
             }
         };
@@ -1309,7 +1428,7 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
 #ifdef RT_PROFILE_PHASES
     if (sort && lane == 0) {
         ph[0] = RT_PHASE_CLOCK() - ph_t0;
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_phase_stats[k], ph[k]);
+        for (int k = 0; k < 10; ++k) atomicAdd(&g_phase_stats[k], ph[k]);
     }
 #endif
     __syncthreads();

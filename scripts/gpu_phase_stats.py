@@ -30,10 +30,12 @@ for name in scenes:
     assert fn(out, 1) == 0
     total = max(out[0], 1)
     print(f"{name}: {st.n_rays} rays, {spp} spp, k_shade past depth 0: {total} wave-ticks (s_memtime) in all")
-    rows = [("sort of a block (hit-record loads, histogram, scatter)", out[1], out[5], "blocks"),
+    rows = [("drain of the previous block's stores (vmcnt(0) on its own)", out[8], out[5], "blocks"),
+            ("  of the sort: hit-record loads issued -> arrived", out[9], out[5], "blocks"),
+            ("sort of a block (hit-record loads, histogram, scatter)", out[1], out[5], "blocks"),
             ("wait for the first segment's rays", out[2], out[5], "blocks"),
             ("all-miss segments", out[3], out[6], "segments"),
             ("segments with hits", out[4], out[7], "segments")]
     for label, ticks, n, unit in rows:
         print(f"  {label:56s} {100.0 * ticks / total:5.1f} %   {n:10d} {unit:8s} {ticks / max(n, 1):9.0f} ticks each")
-    print(f"  {'outside (staging, barriers, tails)':56s} {100.0 * (total - out[1] - out[2] - out[3] - out[4]) / total:5.1f} %")
+    print(f"  {'outside (staging, barriers, tails)':56s} {100.0 * (total - out[1] - out[2] - out[3] - out[4] - out[8]) / total:5.1f} %")

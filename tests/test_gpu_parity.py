@@ -335,13 +335,9 @@ def test_render_config1_random_spheres(rt, orc, renderer):
     assert st.n_paths == so.n_paths == 400 * 225 * 8
     assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
     assert st.n_texture_fetches == so.n_texture_fetches and st.n_bad_dir == so.n_bad_dir == 0
-    e = rmse_display(img, ref)
-    assert e <= RMSE_TOL, e
+    _compare_frames(orc, scene, p, img, ref, "config 1", rt, renderer)  # (the scene holds an image texture: texel-edge lookups are re-traced)
     diff8 = np.abs(rgb8.astype(int) - ref8.astype(int))
     assert diff8.max() <= 1 and (diff8 > 0).mean() < 1e-3
-    # against the wavefront-order (iterative) oracle the agreement is tighter still
-    it, _, _ = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_COUNTER, estimator=orc.EST_ITERATIVE))
-    assert rmse_display(img, it) <= 2e-5
     # and the reference-order stream mode agrees statistically (different random numbers)
     stv, _, _ = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_STREAM))
     assert abs(display(img).mean() - display(stv).mean()) < 5e-3
@@ -354,7 +350,7 @@ def test_render_full_depth_and_slicing_invariance(rt, orc, renderer):
     img, _, st = renderer.render(scene.camera, p)
     ref, _, so = _oracle(orc, scene, p)
     assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
-    assert rmse_display(img, ref) <= RMSE_TOL
+    _compare_frames(orc, scene, p, img, ref, "sphere_scene 256x144x6", rt, renderer)
     # slices of 1, 4 and 6 samples: bit-identical framebuffers (sample order is preserved)
     for s in (1, 4):
         ps = rt.make_params(256, 144, 6, max_depth=50, spp_slice=s)
@@ -422,7 +418,7 @@ def test_tall_narrow_frame_up_to_the_row_limit(rt, orc, renderer):
     img, _, st = renderer.render(scene.camera, p)
     ref, _, so = _oracle(orc, scene, p)
     assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
-    assert rmse_display(img, ref) <= RMSE_TOL
+    _compare_frames(orc, scene, p, img, ref, "test_sphere 1 x (2^21 - 1)", rt, renderer)
     with pytest.raises(rt.RtError, match="2\\^21"):
         renderer.render(scene.camera, rt.make_params(1, 1 << 21, 1, max_depth=4))
     part, _, _ = renderer.render(scene.camera, rt.make_params(1, 1 << 21, 1, max_depth=4, seed=5, shard_band=8, shard_count=2, shard_id=1))
@@ -555,12 +551,17 @@ def _texel_edge_distance(scene, hit, o, d, t):
     fs = scene.flat
     if hit >= 0:
         if hit >= fs.n_spheres:
-            return None
+            return None  # a rectangle's uv is (p - min) / (max - min), plain arithmetic: exact on both sides
         m = fs.sph_mat[hit]
-        if fs.mat_type[m] not in (0, 1, 2, 5, 6, 7, 8, 9, 10, 11) or fs.tex_type[fs.mat_tex0[m]] != 3:  # RT_TEX_IMAGE
+        imgs = []
+        if fs.mat_type[m] in (0, 1, 2, 5, 6, 7, 8, 9, 10, 11) and fs.tex_type[fs.mat_tex0[m]] == 3:  # RT_TEX_IMAGE as tex0
+            imgs.append(fs.tex_aux[fs.mat_tex0[m]])
+        if fs.mat_type[m] == 8 and fs.tex_type[fs.mat_tex1[m]] == 3:                                  # RoughPlastic's diff_color, pbr.rs:172
+            imgs.append(fs.tex_aux[fs.mat_tex1[m]])
+        if not imgs:
             return None
-        img = fs.tex_aux[fs.mat_tex0[m]]
         f = np.float32
+        o, d = _object_space_ray(fs, hit, o.astype(f), d.astype(f))                 # below its wrappers, hitable.rs:411, 483-492
         pnt = (o + (d * f(t)).astype(f)).astype(f)                                   # Ray::at, math.rs:64
         c = np.array([fs.sph_cx[hit], fs.sph_cy[hit], fs.sph_cz[hit]], dtype=f)
         n = ((pnt - c).astype(f) / f(fs.sph_r[hit])).astype(f).astype(np.float64)  # hitable.rs:95
@@ -568,14 +569,41 @@ def _texel_edge_distance(scene, hit, o, d, t):
     else:
         if fs.sky_type != 2:
             return None
-        img, n, flip_u = fs.sky_image, d.astype(np.float64), True
+        imgs, n, flip_u = [fs.sky_image], d.astype(np.float64), True
     theta, phi = np.arccos(-n[1]), np.arctan2(-n[2], n[0]) + np.pi                   # hitable.rs:65-71
     u, v = phi / (2 * np.pi), theta / np.pi
     if flip_u:
         u = 1.0 - u                                                                  # demo_scene.rs:24
-    x = min(max(u, 0.0), 1.0) * fs.img_w[img]
-    y = (1.0 - min(max(v, 0.0), 1.0)) * fs.img_h[img]
-    return min(abs(x - round(x)) / fs.img_w[img], abs(y - round(y)) / fs.img_h[img]) * 2.0 ** 23
+    best = None
+    for img in imgs:
+        x = min(max(u, 0.0), 1.0) * fs.img_w[img]
+        y = (1.0 - min(max(v, 0.0), 1.0)) * fs.img_h[img]
+        dist = min(abs(x - round(x)) / fs.img_w[img], abs(y - round(y)) / fs.img_h[img]) * 2.0 ** 23
+        best = dist if best is None else min(best, dist)
+    return best
+
+
+def _object_space_ray(fs, sphere, o, d):
+    """The ray Sphere::hit receives below the sphere's Translate / RotateY wrappers (outermost first: hitable.rs:411 moves the origin,
+    :483-492 rotates origin and direction), in float32 like both implementations."""
+    f = np.float32
+    chain, x = [], (fs.sph_xform[sphere] if fs.n_xforms and fs.sph_xform else rt_ffi_no_xform())
+    while x != rt_ffi_no_xform():
+        chain.append(x)
+        x = fs.xf_parent[x]
+    for x in reversed(chain):
+        q = [f(fs.xf_param[4 * x + k]) for k in range(4)]
+        if fs.xf_type[x] == 0:
+            o = (o - np.array(q[:3], dtype=f)).astype(f)
+        else:
+            sn, cs = q[0], q[1]
+            o = np.array([f(f(cs * o[0]) - f(sn * o[2])), o[1], f(f(sn * o[0]) + f(cs * o[2]))], dtype=f)
+            d = np.array([f(f(cs * d[0]) - f(sn * d[2])), d[1], f(f(sn * d[0]) + f(cs * d[2]))], dtype=f)
+    return o, d
+
+
+def rt_ffi_no_xform():
+    return 0xFFFFFFFF
 
 
 def _explain_outliers(rt, orc, renderer, scene, p, img, it, name, px_tol=1e-4, edge_ulps=2.0):
@@ -791,7 +819,7 @@ def test_config3_full_size_sharded_8_ways(rt, orc, renderer):
     img, _, s1 = renderer.render(scene.camera, p1)
     ref, _, so = _oracle(orc, scene, p1)
     assert s1.n_rays == so.n_rays and list(s1.rays_per_depth) == list(so.rays_per_depth)
-    assert rmse_display(img, ref) <= RMSE_TOL
+    _compare_frames(orc, scene, p1, img, ref, "config 3 at 1 spp", rt, renderer)
 
 
 def test_in_library_multi_gpu_entry_points(rt, renderer):
@@ -931,7 +959,8 @@ def test_scene_too_large_for_the_lds_bvh_uses_the_list_walk(rt, orc, renderer):
     p = rt.make_params(160, 90, 2, max_depth=10)
     img, _, st = renderer.render(s.camera, p)
     ref, _, so = _oracle(orc, s, p)
-    assert st.n_rays == so.n_rays and rmse_display(img, ref) <= RMSE_TOL
+    assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
+    _compare_frames(orc, s, p, img, ref, "3000 spheres, list walk", rt, renderer)
     o, d, keys = rays_on_scene(4000, 21)
     g = renderer.debug_bounce(o, d, keys)
     c = orc.debug_bounce(s.flat_ptr, o, d, keys, accel=orc.ACCEL_LIST)
@@ -1015,7 +1044,7 @@ def test_rectangles_and_boxes(rt, orc, renderer):
     ref, _, so = _oracle(orc, scene, p, accel=orc.ACCEL_LIST)
     assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
     assert st.n_texture_fetches == so.n_texture_fetches and st.n_texture_fetches > 0
-    assert rmse_display(img, ref) <= RMSE_TOL
+    _compare_frames(orc, scene, p, img, ref, "box room", rt, renderer)
     # the reference's own BvhNode culls with UNPADDED boxes (`t_max <= t_min` rejects, math.rs:109): a hit within an
     # ulp of a rectangle's edge passes XYRect::hit but not the box around it, ~1e-6 of the rays; those paths differ
     bv, _, sb = _oracle(orc, scene, p, accel=orc.ACCEL_BVH)
@@ -1136,7 +1165,8 @@ def test_translate_and_rotate_y_instances(rt, orc, renderer):
     img, _, st = renderer.render(scene.camera, p)
     ref, _, so = _oracle(orc, scene, p, accel=orc.ACCEL_LIST)
     assert st.n_rays == so.n_rays and list(st.rays_per_depth) == list(so.rays_per_depth)
-    assert st.n_texture_fetches == so.n_texture_fetches and rmse_display(img, ref) <= RMSE_TOL
+    assert st.n_texture_fetches == so.n_texture_fetches
+    _compare_frames(orc, scene, p, img, ref, "cornell box with instances", rt, renderer)
 
 
 def test_constant_medium_and_cornell_box(rt, orc, renderer):
@@ -1307,6 +1337,70 @@ def test_primary_candidate_lists_do_not_change_images(rt, renderer):
 
 
 @pytest.mark.gpu
+def test_depth0_closest_hit_launch_is_decided_inside_every_frame(rt):
+    """Depth 0 of a sphere-only scene launches its closest-hit kernel only when some pixel's candidate list overflowed, and
+    rt_render decides that inside the frame (the count k_primary_lists leaves is read back before anything else of the frame
+    is enqueued) — so the first frame of a view is the same work as any later one, and nothing carries over from frame to frame:
+    view A twice, view B, A again, then another scene under the same camera.  Every frame equals the frame of a fresh context bit
+    for bit, equals the frame without candidate lists, has the same rays per depth, and its launch count says whether the
+    closest-hit launch was skipped (RtStats.n_trace_launches: two per depth, less that one).  Once with overflowing lists, once
+    without."""
+    def wall(n_behind, seed):
+        s = rt.Scene.new()
+        red = s.material(rt._ffi.MAT_DIFFUSE, tex0=s.constant_tex((0.8, 0.2, 0.2)))
+        mir = s.material(rt._ffi.MAT_METAL, color=(0.8, 0.8, 0.9), p=(0.05,))
+        s.sphere((0, -1000, 0), 1000.0, red, "ground")
+        rng = np.random.default_rng(seed)
+        for k in range(40):
+            s.sphere((float(rng.uniform(-4, 4)), 0.3, float(rng.uniform(-4, 4))), 0.3, mir if k % 3 else red, "small")
+        for k in range(n_behind):  # a column of spheres behind each other along the view axis: more than 7 candidates per pixel
+            s.sphere((0.0, 1.0, -2.0 - 1.5 * k), 0.6, red, "column")
+        s.set_camera((0, 1.0, 6), (0, 1.0, 0), (0, 1, 0), 35, 1.5)
+        s.finish()
+        return s
+
+    max_depth = 10
+    full = 2 * (max_depth + 1)
+    for n_behind, overflow in ((0, False), (12, True)):
+        sa, sb = wall(n_behind, 3), wall(n_behind, 4)
+        cam_a = sa.camera
+        other = rt.Scene.new()
+        other.set_camera((3, 2.0, 5), (0, 0.5, 0), (0, 1, 0), 40, 1.5)
+        other.finish()
+        cam_b = other.camera
+        p = rt.make_params(150, 100, 8, max_depth=max_depth)
+
+        def fresh(scene, cam, lists=True):
+            r = rt.Renderer(0)
+            if not lists:
+                r.set_option("primary_lists", 1)
+            r.upload(scene)
+            img, _, st = r.render(cam, p)
+            r.close()
+            return img, st
+
+        r = rt.Renderer(0)
+        r.upload(sa)
+        seq = [(sa, cam_a), (sa, cam_a), (sa, cam_b), (sa, cam_a), (sb, cam_a), (sb, cam_a)]
+        current = sa
+        for k, (scene, cam) in enumerate(seq):
+            if scene is not current:
+                r.upload(scene)
+                current = scene
+            img, _, st = r.render(cam, p)
+            ref, st_ref = fresh(scene, cam)
+            plain, st_plain = fresh(scene, cam, lists=False)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (n_behind, k)
+            assert np.array_equal(img.view(np.uint32), plain.view(np.uint32)), (n_behind, k)
+            assert list(st.rays_per_depth) == list(st_ref.rays_per_depth) == list(st_plain.rays_per_depth), (n_behind, k)
+            assert st.n_trace_launches == st_ref.n_trace_launches, (n_behind, k)
+            assert st_plain.n_trace_launches == full
+            if cam is cam_a:  # (view B looks along the column from the side: whether it overflows is not the point)
+                assert st.n_trace_launches == (full if overflow else full - 1), (n_behind, k, st.n_trace_launches)
+        r.close()
+
+
+@pytest.mark.gpu
 def test_config2_full_size_three_searches_agree(rt, renderer):
     """BASELINE config 2 at full size (1920x1080, 256 spp, depth 50): candidate lists, tree and list walk give the same
     frame bit for bit.  Ray counts may differ by the handful of grazing rays for which fp32 Sphere::hit reports a hit
@@ -1415,8 +1509,12 @@ def test_random_scenes_bounce_parity(rt, orc, renderer, seed):
         # near-axis rays above sit exactly on such edges of the 1600x800 environment map (v = 0.5, u = 0.25 / 0.75), so
         # their colours are only compared loosely; for ordinary rays a flip is a 1e-5 event.
         bad = (~np.isclose(a_, c_, rtol=5e-5, atol=2e-6) & fin).any(axis=1)
-        assert bad[n // 50:].mean() < 3e-4, (k, int(bad[n // 50:].sum()), np.abs(a_[fin] - c_[fin]).max())
-        assert np.abs(a_[: n // 50][fin[: n // 50]] - c_[: n // 50][fin[: n // 50]]).max(initial=0.0) < 0.5
+        assert bad[n // 50:].mean() < 1e-3, (k, int(bad[n // 50:].sum()))  # (ordinary rays: a flip is a 1e-5 event; the near-axis ones all sit on edges)
+        for r in np.nonzero(bad)[0]:  # every colour that differs is such a lookup: (u, v) within 2 x 2^-23 of a texel edge, or the test fails
+            if med[r] and g["t"][r] != c["t"][r]:
+                continue  # a medium scatter whose t differs in the last bits (ln): the phase texture is evaluated an ulp away (hitable.rs:560-570)
+            dist = _texel_edge_distance(scene, int(g["hit"][r]), o[r], d[r], g["t"][r])
+            assert dist is not None and dist <= 2.0, (k, "ray", int(r), "hit", int(g["hit"][r]), "colours differ away from a texel edge", dist, a_[r], c_[r])
     # and a small frame through the whole pipeline (queues, lists, media phase) against the oracle
     p = rt.make_params(96, 64, 4, max_depth=6)
     img, _, st = renderer.render(scene.camera, p)
