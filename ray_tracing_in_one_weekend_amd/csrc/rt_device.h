@@ -277,12 +277,6 @@ struct DevScene {
     uint32_t bvh4_depth;
     const float4* bvh4_p[6];
     const int4* bvh4_id;
-    // The same tree in 58 B per node for LDS (general scenes whose float tree does not fit beside a second workgroup,
-    // rt_kernels.h QTree): child planes as halves rounded OUTWARD (per axis one 16 B record: min of the 4 children | max of the 4),
-    // child ids as u16 (inner node | 0x8000 + world entry | 0xFFFF empty), parent node as u16 (root: 0xFFFF).  NULL when not built.
-    const uint4* q_plane[3];
-    const uint2* q_ids;
-    const unsigned short* q_parent;
     // sort key of every world entry: the rank of its shading class (1 + material_type*4 + texture_type of tex0; 0 is
     // "miss") among the classes present in the scene, cheap classes first.  k_shade orders the hit records of a block
     // by this key so that a wave runs one material branch.

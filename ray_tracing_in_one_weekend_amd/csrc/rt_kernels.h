@@ -525,10 +525,6 @@ struct BvhLds {
     uint32_t n_spheres;
     GenTables gt;          // wrapper / medium tables of general scenes (HBM, or LDS with GLDS)
     unsigned short* stack; // this lane's column: stack[level * BLOCK]
-    // QT (stage_qtree): the tree in 58 B per node, in LDS, walked without a stack (bvh_step_q)
-    const uint4* qp[3];
-    const uint2* qid;
-    const unsigned short* qpar;
 };
 
 // LDS_NODES = false: the tree and the primitive geometry stay in HBM (scenes whose tree does not fit the
@@ -732,141 +728,6 @@ __device__ __forceinline__ bool media_step(const BvhLds& L, V3 o, V3 d, const Me
     }
     return pend == 0u;
 }
-// ---------------------------------------------------------------------------------------------------------------------
-// QT: the 4-wide tree of a general scene in LDS at 58 B per node, walked without a stack (round 5).
-//
-// final_scene's tree (1 150 nodes x 112 B) does not fit LDS beside a second 1 024-thread workgroup, and neither do the per-lane
-// stacks (u16 x 3 levels per tree level x 1 024 lanes = 40 KB): until round 4 such a tree was read through L2, seven dependent 16 B
-// gathers per node step.  Here the child planes are halves rounded OUTWARD (a box only ever grows: culling stays conservative, the
-// exact leaf tests decide as before), the child ids are u16, and what a lane has still to visit is a 64-bit TRAIL instead of a
-// stack: four bits per tree level — the inner children of that level's node that were hit but not entered — under a sentinel bit.
-// A node step tests the four child boxes against [0, tbest] exactly like bvh_step, tests the hit leaves, enters the nearest hit
-// inner child and leaves the other hit ones in the trail; a lane that has nothing to enter climbs (u16 parent links) to the
-// first level whose nibble is not empty and enters the lowest child noted there.  The visiting order is the stack version's
-// up to the order among siblings, and the winner rule does not depend on it.  (A sibling is not re-tested against the tbest
-// of the moment it is finally entered — the stack version does not do that either.)
-#define RT_QT_EMPTY 0xFFFFu
-#define RT_QT_LEAF 0x8000u
-#define RT_QT_MAX_DEPTH 15u // 4 bits per level + the sentinel in 64 bits
-__host__ __device__ inline size_t qtree_lds_bytes(uint32_t n_nodes) { return (((size_t)n_nodes * 58u + 15u) & ~(size_t)15u) + 16u; }
-template <int BLOCK>
-__device__ __forceinline__ BvhLds stage_qtree(const DevScene& sc, char* smem) {
-    const uint32_t n = sc.n_bvh4_nodes;
-    BvhLds L;
-    uint4* pl = reinterpret_cast<uint4*>(smem);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        for (uint32_t i = threadIdx.x; i < n; i += BLOCK) pl[(size_t)a * n + i] = sc.q_plane[a][i];
-        L.qp[a] = pl + (size_t)a * n;
-    }
-    uint2* ids = reinterpret_cast<uint2*>(pl + 3u * (size_t)n);
-    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) ids[i] = sc.q_ids[i];
-    unsigned short* par = reinterpret_cast<unsigned short*>(ids + n);
-    for (uint32_t i = threadIdx.x; i < n; i += BLOCK) par[i] = sc.q_parent[i];
-    L.qid = ids, L.qpar = par;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) L.pl[a] = sc.bvh4_p[a];
-    L.id = sc.bvh4_id;
-    L.geo = sc.prim_geo; // leaf geometry stays in HBM / L2
-    L.n_spheres = sc.n_spheres;
-    L.gt = tables_of(sc);
-    L.stack = nullptr;
-    return L;
-}
-__device__ __forceinline__ float4 halves_lo(uint4 v) { // the four halves of (x, y) as floats
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y);
-    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
-}
-__device__ __forceinline__ float4 halves_hi(uint4 v) { // the four halves of (z, w)
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 a = __builtin_bit_cast(h2, v.z), b = __builtin_bit_cast(h2, v.w);
-    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
-}
-// One traversal step of one lane on the quantised tree; `trail` as described above (1 = at the root, nothing noted).
-// Returns true when the traversal of this ray has finished.
-template <bool RECTS>
-__device__ __forceinline__ bool bvh_step_q(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float nox, float noy, float noz,
-                                           float eps, bool exact, float a, uint32_t& pend, int& cur, unsigned long long& trail,
-                                           float& tbest, int& hit) {
-    {
-        RT_LANE_STAT(2, true);
-        const uint4 qx = L.qp[0][cur], qy = L.qp[1][cur], qz = L.qp[2][cur];
-        const uint2 qi = L.qid[cur];
-        const float4 mnx = halves_lo(qx), mxx = halves_hi(qx), mny = halves_lo(qy), mxy = halves_hi(qy), mnz = halves_lo(qz), mxz = halves_hi(qz);
-        const uint32_t idv[4] = {qi.x & 0xFFFFu, qi.x >> 16, qi.y & 0xFFFFu, qi.y >> 16};
-        const float tb = __builtin_fmaf(tbest, 1.000004f, eps);
-        uint32_t lq0 = 0u, lq1 = 0u; // the hit leaf children of this node, entry id + 1 in 16 bits each
-        float best_t = RT_FLT_MAX;
-        uint32_t best = RT_QT_EMPTY, best_slot = 0u, others = 0u;
-#define RT_CHILD_Q(K, S)                                                                                      \
-    {                                                                                                         \
-        const uint32_t idk = idv[S];                                                                          \
-        const float x0 = RT_T(mnx.K, ix, nox, o.x), x1 = RT_T(mxx.K, ix, nox, o.x);                           \
-        const float y0 = RT_T(mny.K, iy, noy, o.y), y1 = RT_T(mxy.K, iy, noy, o.y);                           \
-        const float z0 = RT_T(mnz.K, iz, noz, o.z), z1 = RT_T(mxz.K, iz, noz, o.z);                           \
-        const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));              \
-        const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));                           \
-        if (tn <= fminf(__builtin_fmaf(tf, 1.000004f, eps), tb) && idk != RT_QT_EMPTY) {                      \
-            if (idk & RT_QT_LEAF) { /* a leaf: queued for the leaf loop behind the four box tests */          \
-                lq1 = (lq1 << 16) | (lq0 >> 16);                                                               \
-                lq0 = (lq0 << 16) | ((idk & 0x7FFFu) + 1u);                                                    \
-            } else if (tn < best_t) { /* new nearest: the previous nearest (if any) is noted in the trail */  \
-                if (best != RT_QT_EMPTY) others |= 1u << best_slot;                                            \
-                best_t = tn, best = idk, best_slot = S;                                                        \
-            } else {                                                                                          \
-                others |= 1u << S;                                                                             \
-            }                                                                                                 \
-        }                                                                                                     \
-    }
-        if (!exact) {
-#define RT_T(B, INV, NO, O) __builtin_fmaf(B, INV, NO)
-            RT_CHILD_Q(x, 0)
-            RT_CHILD_Q(y, 1)
-            RT_CHILD_Q(z, 2)
-            RT_CHILD_Q(w, 3)
-#undef RT_T
-        } else { // rays almost parallel to an axis plane (see k_intersect): plane distances without cancellation
-#define RT_T(B, INV, NO, O) (((B) - (O)) * (INV))
-            RT_CHILD_Q(x, 0)
-            RT_CHILD_Q(y, 1)
-            RT_CHILD_Q(z, 2)
-            RT_CHILD_Q(w, 3)
-#undef RT_T
-        }
-#undef RT_CHILD_Q
-        ChainCache cc;
-        cc.xf = RT_NO_XFORM_DEV;
-        while (lq0 != 0u) {
-            RT_LANE_STAT(4, true);
-            const int s = (int)(lq0 & 0xFFFFu) - 1;
-            lq0 = (lq0 >> 16) | (lq1 << 16);
-            lq1 >>= 16;
-            leaf_test<RECTS>(L, s, o, d, a, pend, tbest, hit, RECTS ? &cc : nullptr);
-        }
-        if (best != RT_QT_EMPTY) {
-            trail = (trail << 4) | others;
-            cur = (int)best;
-            return false;
-        }
-    }
-    // nothing to enter below this node: climb to the first level that has a child noted, enter the lowest one
-    while (trail != 1ull) { // (at most RT_QT_MAX_DEPTH trips)
-        const uint32_t m = (uint32_t)trail & 15u;
-        cur = (int)L.qpar[cur];
-        if (m) {
-            const uint32_t s = (uint32_t)__ffs((int)m) - 1u;
-            trail = (trail & ~15ull) | (m & (m - 1u));
-            const uint2 qi = L.qid[cur];
-            const uint32_t w2 = s < 2u ? qi.x : qi.y;
-            cur = (int)((s & 1u) ? w2 >> 16 : w2 & 0xFFFFu); // (its own node step pushes its level)
-            return false;
-        }
-        trail >>= 4;
-    }
-    return true;
-}
-
 struct IntersectParams {
     uint32_t nq, cap;
     int depth;
@@ -882,7 +743,7 @@ struct IntersectParams {
 // 1024-thread workgroups (8 waves per SIMD) share a CU and hide each other's dependent node fetches
 // — measured +15 % on cornell_box and +20 % on final_scene against 7 waves = one workgroup.
 // GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
-template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES, bool GLDS, bool QT = false>
+template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES, bool GLDS>
 __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float4* __restrict__ qa,
                                                      const float4* __restrict__ qb,
                                                      float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
@@ -902,10 +763,9 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
     const uint32_t total = pre[RT_ISECT_MAX_SHARDS];
     if (total == 0) return; // block-uniform
     if (GEN && !RECTS && gpd->lists && *gpd->n_overflow == 0u) return; // every pixel has a list: k_shade<GEN> finds all closest hits of depth 0
-    const size_t tree_bytes = QT ? qtree_lds_bytes(sc.n_bvh4_nodes) : bvh_lds_bytes(sc, BLOCK, LDS_NODES);
-    BvhLds L = QT ? stage_qtree<BLOCK>(sc, smem) : stage_bvh<BLOCK, LDS_NODES>(sc, smem);
-    if (GLDS) L.gt = stage_general<BLOCK>(sc, smem + tree_bytes);
-    uint32_t* s_work = reinterpret_cast<uint32_t*>(smem + tree_bytes - 16u);
+    BvhLds L = stage_bvh<BLOCK, LDS_NODES>(sc, smem);
+    if (GLDS) L.gt = stage_general<BLOCK>(sc, smem + bvh_lds_bytes(sc, BLOCK, LDS_NODES));
+    uint32_t* s_work = reinterpret_cast<uint32_t*>(smem + bvh_lds_bytes(sc, BLOCK, LDS_NODES) - 16u);
     if (threadIdx.x == 0) *s_work = 0u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
@@ -918,7 +778,6 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
     V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
     float ix = 0.f, iy = 0.f, iz = 0.f, nox = 0.f, noy = 0.f, noz = 0.f, eps = 0.f, a = 1.0f, tbest = RT_FLT_MAX;
     int hit = -1, cur = 0, sp = 0;
-    unsigned long long trail = 1ull; // QT: what this lane has still to visit (bvh_step_q)
     size_t pos = 0;
     MediumCtx mc{0u, 0u, depth_counter_base(ip.depth)};
     // Sorted slab planes for sphere-only scenes with the tree in LDS.  General scenes: the six extra registers spill in the
@@ -989,7 +848,6 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 hit = -1;
                 cur = 0;
                 sp = 0;
-                trail = 1ull;
                 has = !no_geometry;
                 trav = true;
                 pend = 0u;
@@ -1029,8 +887,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 continue;
             }
         }
-        if (has && trav && (QT ? bvh_step_q<RECTS>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, trail, tbest, hit)
-                               : bvh_step<BLOCK, RECTS, SORTED>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit, &planes))) {
+        if (has && trav && bvh_step<BLOCK, RECTS, SORTED>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit, &planes)) {
             if (RECTS && pend) {
                 trav = false;
             } else {
