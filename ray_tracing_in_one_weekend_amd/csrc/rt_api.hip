@@ -952,6 +952,8 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     unsigned long long* totals = (unsigned long long*)ctx->totals.p; // [0]=tex fetches [1]=bad dirs [2..]=rays per depth
 
+    // (before the frame's own clock starts: once per launch stream, 0.3 ms of spin kernels; see ensure_concurrent_chains)
+    if (nq >= 2u * RT_ISECT_MAX_SHARDS && (rc = ensure_concurrent_chains(ctx, st))) return rc;
     RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
     RT_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * 3 * sizeof(float), st));
     RT_HIP(ctx, hipMemsetAsync(totals, 0, totals_bytes, st));
@@ -1037,7 +1039,6 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t chains_opt = ctx->opt[RT_OPT_CHAINS];
     const bool one_chain = chains_opt ? chains_opt == 1u : (ctx->ds.n_xforms > 0 || ctx->ds.n_media > 0 || (use_bvh && !ctx->bvh_in_lds));
     const uint32_t n_groups = (nq >= 2u * RT_ISECT_MAX_SHARDS && !time_depths && !one_chain) ? 2u : 1u;
-    if (n_groups > 1u && (rc = ensure_concurrent_chains(ctx, st))) return rc;
     const uint32_t shards_per_wg = (nq + isect_grid - 1u) / isect_grid;
     // selects the "general scene" kernel instantiations (rectangles and Translate / RotateY wrappers)
     const bool rects = scene_is_general(ctx);

@@ -32,6 +32,11 @@ GROUPS = {
     # (a pass over the TA counters TA_ADDR_STALLED_BY_TC_CYCLES, TA_DATA_STALLED_BY_TC_CYCLES, TA_TA_BUSY, TA_TOTAL_WAVEFRONTS never
     # returned on this pool, round 5: killed after 7 silent minutes; left out)
     "grbm": ["GRBM_GUI_ACTIVE", "GRBM_UTCL2_BUSY"],
+    # the wave's side of the vector-memory path: SQ_INST_LEVEL_VMEM / SQ_INSTS_VMEM = mean cycles a vector-memory instruction is outstanding
+    "sqmem": ["SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INST_LEVEL_VMEM", "SQ_VMEM_TA_ADDR_FIFO_FULL", "SQ_VMEM_TA_CMD_FIFO_FULL",
+              "SQ_VMEM_WR_TA_DATA_FIFO_FULL", "SQ_INST_CYCLES_VMEM_RD", "SQ_INST_CYCLES_VMEM_WR"],
+    "sqmix": ["SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CU_CYCLES",
+              "SQ_CYCLES", "SQ_WAVE_CYCLES"],
 }
 only = os.environ.get("RTOW_PMC_GROUPS")
 if only:
@@ -107,4 +112,11 @@ for name, v in tot.items():
           f"UTCL2 credits {g('TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS'):.3e} serialisation {g('TCP_UTCL1_SERIALIZATION_STALL'):.3e} thrashing {g('TCP_UTCL1_THRASHING_STALL'):.3e}")
     print(f"   L1: pending stall {g('TCP_PENDING_STALL_CYCLES'):.3e}  TCR stall {g('TCP_TCR_TCP_STALL_CYCLES'):.3e}  active {g('TCP_GATE_EN1'):.3e}  accesses {g('TCP_TOTAL_ACCESSES'):.3e}")
     print(f"   TA: busy {g('TA_TA_BUSY'):.3e}  address stalled by TC {g('TA_ADDR_STALLED_BY_TC_CYCLES'):.3e}  data stalled by TC {g('TA_DATA_STALLED_BY_TC_CYCLES'):.3e}  wavefronts {g('TA_TOTAL_WAVEFRONTS'):.3e}")
+    vm = max(g("SQ_INSTS_VMEM_RD") + g("SQ_INSTS_VMEM_WR"), 1.0)
+    print(f"   SQ: vector-memory instructions {vm:.3e} (loads {g('SQ_INSTS_VMEM_RD'):.3e}), mean time outstanding {g('SQ_INST_LEVEL_VMEM') / vm:.0f} cycles; "
+          f"TA address FIFO full {g('SQ_VMEM_TA_ADDR_FIFO_FULL'):.3e}  command FIFO full {g('SQ_VMEM_TA_CMD_FIFO_FULL'):.3e}  write-data FIFO full {g('SQ_VMEM_WR_TA_DATA_FIFO_FULL'):.3e}; "
+          f"issue cycles loads {g('SQ_INST_CYCLES_VMEM_RD'):.3e} stores {g('SQ_INST_CYCLES_VMEM_WR'):.3e}")
+    print(f"   SQ: vector instructions {g('SQ_INSTS_VALU'):.3e}: transcendental f32 {g('SQ_INSTS_VALU_TRANS_F32') / max(g('SQ_INSTS_VALU'), 1):.3f}  int32 {g('SQ_INSTS_VALU_INT32') / max(g('SQ_INSTS_VALU'), 1):.3f}  "
+          f"conversions {g('SQ_INSTS_VALU_CVT') / max(g('SQ_INSTS_VALU'), 1):.3f}; SQ_ACTIVE_INST_VALU {g('SQ_ACTIVE_INST_VALU'):.3e}  SQ_BUSY_CU_CYCLES {g('SQ_BUSY_CU_CYCLES'):.3e}  "
+          f"SQ_CYCLES {g('SQ_CYCLES'):.3e}  SQ_WAVE_CYCLES {g('SQ_WAVE_CYCLES'):.3e}")
     print(f"   GRBM: active {g('GRBM_GUI_ACTIVE'):.3e}  UTCL2 busy {g('GRBM_UTCL2_BUSY'):.3e}   dispatch time {g('us:' + next(iter(data))) / 1e3:.2f} ms")
