@@ -11,11 +11,11 @@ Metric (BASELINE.json): Mray/s (primary + secondary) on demo_scene.rs `sphere_sc
 A "step" is one full render of the frame: every pixel x every sample through the wavefront kernels
 (k_primary_lists, then per depth k_intersect -> k_shade, k_resolve per slice, k_finalize), framebuffer resident in
 HBM.  With N > 1 ranks (one process per GPU, torch.distributed, backend nccl == RCCL over xGMI) the image rows are
-sharded in interleaved bands of 8 rows and each step ends with the all_gather of the band buffers.
+sharded in interleaved bands of 8 rows and each step ends with the gather of the band buffers to rank 0.
     --scaling weak    (default for config 2) per-GPU work fixed: every rank renders (ny/N rows) x nx x spp*N samples
     --scaling strong  (default for configs 3-5) the stated frame split over the N ranks
 With N > 1 and no --config the line is config 3 strong, and a short config-2 weak leg (2 steps) rides along under "also";
-the line carries the gather time per step ("gather_ms", HIP events around the all_gather + de-interleave) and the trace-step
+the line carries the gather time per step ("gather_ms", HIP events around the gather + rank 0's de-interleave) and the trace-step
 HBM fraction of every rank ("roofline.per_rank").
 
 `python bench.py --gpus N` without a torchrun environment starts the N rank processes itself (a child
@@ -23,6 +23,7 @@ HBM fraction of every rank ("roofline.per_rank").
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) including
   "roofline":     trace-step algorithmic HBM bytes / its device time (HIP events on the launch stream)
+  "first_frame":  a fresh process's rt_ctx_create + scene build + rt_scene_upload + first rt_render ("first_frame_ms"), "alloc_bytes"
   "cpu_baseline": the CPU oracle in reference (stream) order, all host cores, bounded sample; built -O3 -march=native on
                   the box it is timed on when g++ is there (BASELINE.md's recipe), else the prebuilt -march=x86-64-v2 library
 """
@@ -117,7 +118,7 @@ PORTABLE_FLAGS = "-O3 -march=x86-64-v2 -ffp-contract=off -fno-fast-math (prebuil
 def native_oracle():
     """BASELINE.md times the CPU reference as `-O3 -march=native`; the oracle that travels with the snapshot is built
     -march=x86-64-v2 so that it runs on any host.  For the timed baseline the same source is compiled once more ON the box
-    that times it (oracle/_native/, git-ignored scratch; ~20 s of g++).  Returns (path, flags) or (None, None)."""
+    that times it (oracle/_native/, git-ignored scratch; 1-3 s of g++).  Returns (path, flags) or (None, None)."""
     import shutil
     cxx = shutil.which("g++")
     if not cxx:

@@ -1,12 +1,12 @@
 """Rewrites the generated block of DESIGN.md section 6 (between `<!-- numbers:begin -->` and `<!-- numbers:end -->`) and the
-headline sentence of README.md from profiles/round4 (run after scripts/gpu_round_profiles.sh + copying its files there), so
+headline sentence of README.md from profiles/round5 (run after scripts/gpu_round_profiles.sh + copying its files there), so
 that no current number in those files is typed by hand."""
 import json
 import os
 import re
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(root, "profiles", "round4") + "/"
+P = os.path.join(root, "profiles", "round5") + "/"
 
 
 def sp(x):
@@ -17,11 +17,11 @@ b2 = json.load(open(P + "bench_config2.json"))
 t2 = json.load(open(P + "traffic_config2.json")) if os.path.exists(P + "traffic_config2.json") else None
 v2 = json.load(open(P + "valu_config2.json"))["kernels"] if os.path.exists(P + "valu_config2.json") else None
 cb = b2["cpu_baseline"]
-block = (f"| round 4: uniform grid for depth ≥ 1, exact early-out in `sphere_root` | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
+block = (f"| round 5: the depth-0 launch decided inside the frame, two chains on two hardware queues, hit-record loads in one round trip (another box: ±2 %) | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
          f"{100 * b2['roofline']['frac']:.1f} % |\n"
          f"| CPU oracle, stream order + BVH, {cb['cores']} host cores (EPYC 9575F), the faster of the portable and the `-march=native` build | "
          f"{cb['value']:.1f} | — | — |\n\n"
-         f"(`profiles/round4/bench_config2.json`: `python bench.py --steps 20 --warmup 5`, build `{b2['library_build_id']}`; CPU builds probed: "
+         f"(`profiles/round5/bench_config2.json`: `python bench.py --steps 20 --warmup 5`, build `{b2['library_build_id']}`; CPU builds probed: "
          + "; ".join(f"{k.split(' (')[0]}: {v} Mray/s at 1 spp" for k, v in cb.get("builds_probed", {}).items()) + ".)\n\n"
          f"`roofline.frac` = algorithmic bytes of the trace step / its device time / 8 TB/s = {sp(b2['roofline']['achieved'])} GB/s / 8 000; whole path "
          f"(96 B / ray + 24 B / path) {b2['whole_path']['hbm_frac']:.3f}.  The kernels are bound by vector issue (section 4), so the honest companion is the VALU "
@@ -33,7 +33,16 @@ if t2:
     block += (f"Measured traffic (PMC, FETCH x 2 + WRITE): {sp(t2['trace_step_bytes_per_launch'] / 1e6)} MB per launch = "
               f"{t2['traffic_over_algorithmic']:.3f} x the algorithmic bytes.  ")
 block += (f"Handed to the host as the reference's output is (f32 frame + flipped RGB8 through `rt_render` into page-locked memory): "
-          f"{sp(b2['value_host_inclusive'])} Mray/s ({100 * (b2['value_host_inclusive'] / b2['value'] - 1):+.1f} %; `value_host_inclusive`, never `value`).\n")
+          f"{sp(b2['value_host_inclusive'])} Mray/s ({100 * (b2['value_host_inclusive'] / b2['value'] - 1):+.1f} %; `value_host_inclusive`, never `value`).  ")
+ff = b2.get("first_frame") or {}
+if ff.get("first_frame_ms"):
+    pm = ff["parts_ms"]
+    block += (f"What the reference's own timer covers — one frame per process (`main.rs:62-129`) — in a process of its own: `first_frame_ms` = {ff['first_frame_ms']:.0f} ms "
+              f"(`rt_ctx_create` {pm['rt_ctx_create']:.0f}, host scene build {pm['scene_build_host']:.0f}, `rt_scene_upload` {pm['rt_scene_upload']:.0f}, first `rt_render` {pm['first_rt_render']:.0f} "
+              f"of which {ff['first_render_device_ms']:.1f} ms on the device against {ff['second_render_device_ms']:.1f} for the second frame, {ff['first_render_trace_launches']} trace launches both), "
+              f"`alloc_bytes` = {ff['alloc_bytes'] / 1e9:.1f} GB.\n")
+else:
+    block += "\n"
 p = os.path.join(root, "DESIGN.md")
 s = open(p).read()
 s = re.sub(r"<!-- numbers:begin -->.*<!-- numbers:end -->", lambda m: "<!-- numbers:begin -->\n" + block + "<!-- numbers:end -->", s, flags=re.S)
