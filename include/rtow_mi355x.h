@@ -298,6 +298,11 @@ void rt_host_free(void* p);
  * rows_local*nx*3 floats (e.g. the storage of a tensor that RCCL will gather).  `stream`
  * is a hipStream_t (NULL = the context's own stream); the call returns after the work has
  * been enqueued and `stats` (if not NULL) forces a synchronisation to read the counters.
+ * A sphere-only scene synchronises `stream` once more, 0.1 ms into the frame: the number of
+ * pixels whose primary-ray candidate list overflowed decides on the host whether depth 0 needs
+ * a closest-hit launch (none does in any headline configuration).  The first frame on a stream
+ * is preceded by ~0.3 ms of spin kernels that check that the library's second stream runs
+ * beside it (two streams on one hardware queue would run the two halves of a slice in turn).
  */
 int rt_render_device(RtCtx* ctx, const RtCamera* cam, const RtParams* params,
                      void* d_out_rgb_f32, void* stream, RtStats* stats);

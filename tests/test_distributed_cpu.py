@@ -133,3 +133,12 @@ def test_bench_record_of_a_two_rank_run():
     assert rec["value"] == 8000.0 and rec["ms_per_step"] == 250.0 and rec["gather_ms"] == 0.4 and rec["rccl_ranks"] == 2
     assert rec["roofline"]["frac"] == 0.25 and [q["frac"] for q in rec["roofline"]["per_rank"]] == [0.25, 0.2]
     assert "RCCL gather to rank 0" in rec["config"]["workload"] and rec["config"]["paths_per_step"] == 3840 * 2160 * 1024
+
+
+def test_bench_first_frame_leg_reports_instead_of_raising():
+    """bench.first_frame runs the cold frame (context + scene build + upload + first render) in a process of its own; where that
+    process cannot render (no GPU here) the bench line gets an "error" entry under "first_frame", never an exception or a hang."""
+    sys.path.insert(0, ROOT)
+    import bench
+    ff = bench.first_frame(2, 64, 36, 1, 4, timeout_s=120.0)
+    assert isinstance(ff, dict) and ("error" in ff or ff.get("first_frame_ms", 0) > 0)
