@@ -383,7 +383,9 @@ enum RtDebugOption {
     RT_OPT_QUEUE_SHARDS = 9,          /* n: queue shards (default 8 per CU) */
     RT_OPT_ISECT_WORKGROUPS = 10,     /* n: closest-hit workgroups per launch */
     RT_OPT_MATERIALISE_PRIMARIES = 11,/* 1: primary rays are written to the queue by their own kernel instead of regenerated */
-    RT_OPT__COUNT = 12
+    RT_OPT_MEDIUM_SEARCH = 12,        /* (upload) 1: ConstantMedium::hit evaluates its boundary twice, as the reference does, also where one
+                                       * evaluation answers both searches (a box, a sphere) */
+    RT_OPT__COUNT = 13
 };
 int rt_debug_set_option(RtCtx* ctx, uint32_t option, uint32_t value);
 int rt_debug_get_option(const RtCtx* ctx, uint32_t option, uint32_t* value);

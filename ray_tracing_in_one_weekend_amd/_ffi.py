@@ -99,11 +99,12 @@ RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C
 MULTI_COPY_GATHER = 1  # RT_MULTI_COPY_GATHER (rt_multi_create_ex)
 # enum RtDebugOption (rt_debug_set_option): per context, every setting renders the same bits
 (OPT_TREE_PLACEMENT, OPT_PRIMARY_LISTS, OPT_PIXEL_ORDER, OPT_TEXEL_POOL, OPT_GRID, OPT_GRID_CELL, OPT_CHAINS,
- OPT_GENERAL_KERNELS, OPT_GENERAL_LDS, OPT_QUEUE_SHARDS, OPT_ISECT_WORKGROUPS, OPT_MATERIALISE_PRIMARIES) = range(12)
+ OPT_GENERAL_KERNELS, OPT_GENERAL_LDS, OPT_QUEUE_SHARDS, OPT_ISECT_WORKGROUPS, OPT_MATERIALISE_PRIMARIES, OPT_MEDIUM_SEARCH) = range(13)
 OPT_NAMES = {"tree_placement": OPT_TREE_PLACEMENT, "primary_lists": OPT_PRIMARY_LISTS, "pixel_order": OPT_PIXEL_ORDER,
              "texel_pool": OPT_TEXEL_POOL, "grid": OPT_GRID, "grid_cell": OPT_GRID_CELL, "chains": OPT_CHAINS,
              "general_kernels": OPT_GENERAL_KERNELS, "general_lds": OPT_GENERAL_LDS, "queue_shards": OPT_QUEUE_SHARDS,
-             "isect_workgroups": OPT_ISECT_WORKGROUPS, "materialise_primaries": OPT_MATERIALISE_PRIMARIES}
+             "isect_workgroups": OPT_ISECT_WORKGROUPS, "materialise_primaries": OPT_MATERIALISE_PRIMARIES,
+             "medium_search": OPT_MEDIUM_SEARCH}
 
 
 class RtSceneInfo(C.Structure):

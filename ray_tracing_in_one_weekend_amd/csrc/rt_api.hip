@@ -716,6 +716,16 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
                 for (int k = 0; k < 3; ++k) mb.mn[k] = std::min(mb.mn[k], pboxes[i].mn[k]), mb.mx[k] = std::max(mb.mx[k], pboxes[i].mx[k]);
             }
         if (med_range[m].y == 0) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: medium " + std::to_string(m) + " has no boundary primitives");
+        if (med_range[m].y > RT_MED_COUNT_MASK) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: medium " + std::to_string(m) + " has too many boundary primitives");
+        {   // boundaries whose two searches are answered from one evaluation of their primitives (medium_root, rt_kernels.h)
+            bool all_rects = true;
+            for (uint32_t k = 0; k < med_range[m].y; ++k) all_rects = all_rects && med_prims[med_range[m].x + k] >= s->n_spheres;
+            uint32_t kind = 0u;
+            if (med_xf[m] != RT_MED_XF_MIXED && all_rects && med_range[m].y <= 6u) kind = RT_MED_KIND_RECTS;
+            else if (med_xf[m] != RT_MED_XF_MIXED && med_range[m].y == 1u && med_prims[med_range[m].x] < s->n_spheres) kind = RT_MED_KIND_SPHERE;
+            if (ctx->opt[RT_OPT_MEDIUM_SEARCH] == 1u) kind = 0u; // test hook: the two searches as the reference makes them
+            med_range[m].y |= kind << 24;
+        }
         eboxes.push_back(mb);
         entry_ids.push_back(n_prims + m);
     }

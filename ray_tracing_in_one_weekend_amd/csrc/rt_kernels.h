@@ -362,6 +362,10 @@ __device__ __forceinline__ bool prim_root_cached(const Tables& sc, const float4*
     const uint32_t gi = sc.n_spheres + 2u * (s - sc.n_spheres);
     return rect_root(geo[gi], geo[gi + 1u], o, d, t_min, t_max, th);
 }
+// med_range[m] = (first entry in med_prims, count | kind << 24): see "ConstantMedium::hit searches its boundary twice" below
+#define RT_MED_KIND_RECTS 1u
+#define RT_MED_KIND_SPHERE 2u
+#define RT_MED_COUNT_MASK 0x00FFFFFFu
 // Root of one boundary primitive for a ray that is already in the object space of the medium's common chain
 // (RAW) or still in world space (the primitive applies its own chain).
 template <bool RAW, class Tables>
@@ -378,7 +382,7 @@ __device__ __forceinline__ bool boundary_root(const Tables& sc, const float4* ge
                                               float t_max, float& t_out) {
     const uint2 rg = sc.med_range[m];
     bool any = false;
-    for (uint32_t k = 0; k < rg.y; ++k) {
+    for (uint32_t k = 0; k < (rg.y & RT_MED_COUNT_MASK); ++k) {
         float th;
         if (boundary_prim_root<RAW>(sc, geo, sc.med_prims[rg.x + k], o, d, t_min, t_max, th)) {
             t_max = th;
@@ -389,6 +393,76 @@ __device__ __forceinline__ bool boundary_root(const Tables& sc, const float4* ge
     return any;
 }
 #define RT_MED_XF_MIXED 0xFFFFFFFEu // the boundary's primitives do not share one wrapper chain
+// ConstantMedium::hit searches its boundary twice (hitable.rs:541-552: `boundary.hit(r, -inf, inf)`, then `boundary.hit(r, t1 + 0.0001,
+// inf)`), and a search of a GBox is six rectangle tests.  Where a rectangle's plane distance and its bounds test, or a sphere's two
+// roots, do not depend on the search window, both searches can be answered from ONE evaluation of the primitives: the candidates are
+// computed once and the two windows — with HitableList::hit's shrinking t_max (hitable.rs:117-132), comparison for comparison — are
+// applied to the stored values.  Same operations on the same operands as rect_root / sphere_root, so the same bits; half the
+// arithmetic of a medium test (cornell_box spends a third of its closest-hit time in its two smoke boxes).  rt_scene_upload marks
+// the boundaries this applies to in the top byte of med_range[m].y: up to six rectangles, or one sphere, below one wrapper chain.
+__device__ __forceinline__ bool in_window(float t, float t_min, float t_max) { return !(t < t_min || t_max < t); }
+// both searches over <= 6 rectangles in object space; false when either finds nothing or the medium is entered behind t_cull
+template <class Tables>
+__device__ __forceinline__ bool boundary_both_rects(const Tables& sc, const float4* geo, uint2 rg, V3 o, V3 d, float t_cull, float& t1, float& t2) {
+    const uint32_t n = rg.y & RT_MED_COUNT_MASK;
+    float tk[6]; // plane distance of rectangle k where it passes XYRect::hit's tests that do not involve the window, else NaN
+#pragma unroll
+    for (uint32_t k = 0; k < 6u; ++k) {
+        tk[k] = __int_as_float(0x7FC00000);
+        if (k < n) {
+            const uint32_t s = sc.med_prims[rg.x + k];
+            const uint32_t gi = sc.n_spheres + 2u * (s - sc.n_spheres);
+            const float4 g0 = geo[gi], g1 = geo[gi + 1u];
+            const uint32_t axis = __float_as_uint(g1.y);
+            const float oa = axis == 0u ? o.x : (axis == 1u ? o.y : o.z);
+            const float da = axis == 0u ? d.x : (axis == 1u ? d.y : d.z);
+            const float t = (g0.x - oa) / da;       // rect_root, hitable.rs:252
+            const V3 p = o + d * t;                 // Ray::at
+            const float pu = axis == 0u ? p.y : p.x;
+            const float pv = axis == 2u ? p.y : p.z;
+            if (t == t && !(pu < g0.y || pu > g0.z || pv < g0.w || pv > g1.x)) tk[k] = t;
+        }
+    }
+    // boundary.hit(r, -inf, inf): rect_root's window test `t < t_min || t > t_max` with t_max shrinking to every accepted root
+    float t_max = INFINITY;
+    bool any = false;
+#pragma unroll
+    for (uint32_t k = 0; k < 6u; ++k)
+        if (tk[k] == tk[k] && !(tk[k] < -INFINITY || tk[k] > t_max)) t_max = tk[k], any = true;
+    if (!any) return false;
+    t1 = t_max;
+    if (t1 > t_cull) return false;
+    const float t_min2 = t1 + 0.0001f; // boundary.hit(r, rec1.t + 0.0001, inf)
+    t_max = INFINITY, any = false;
+#pragma unroll
+    for (uint32_t k = 0; k < 6u; ++k)
+        if (tk[k] == tk[k] && !(tk[k] < t_min2 || tk[k] > t_max)) t_max = tk[k], any = true;
+    t2 = t_max;
+    return any;
+}
+// both searches of a boundary that is one sphere: Sphere::hit's two roots (hitable.rs:75-91) once, its window logic twice
+template <class Tables>
+__device__ __forceinline__ bool boundary_both_sphere(const Tables& sc, const float4* geo, uint2 rg, V3 o, V3 d, float t_cull, float& t1, float& t2) {
+    const float4 g = geo[sc.med_prims[rg.x]];
+    const float a = length_squared(d);
+    const V3 oc = o - v3(g.x, g.y, g.z);
+    const float half_b = dot(oc, d);
+    const float c = length_squared(oc) - g.w * g.w;
+    const float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0f) return false;
+    const float sqrtd = sqrtf(discriminant);
+    const float r0 = (-half_b - sqrtd) / a, r1 = (-half_b + sqrtd) / a;
+    // (sphere_root's early-out for a sphere behind the origin only skips arithmetic whose roots fail the window below: rt_device.h)
+    if (in_window(r0, -INFINITY, INFINITY)) t1 = r0;
+    else if (in_window(r1, -INFINITY, INFINITY)) t1 = r1;
+    else return false;
+    if (t1 > t_cull) return false;
+    const float t_min2 = t1 + 0.0001f;
+    if (in_window(r0, t_min2, INFINITY)) t2 = r0;
+    else if (in_window(r1, t_min2, INFINITY)) t2 = r1;
+    else return false;
+    return true;
+}
 // ConstantMedium::hit, hitable.rs:536-579, up to the accepted t.  The random draw is counter slot
 // 224 + m of the depth block (DESIGN.md "RNG"): independent of the order in which media are visited.
 // t_max clamps like the reference's (hitable.rs:553-555); callers pass FLT_MAX and apply the
@@ -405,9 +479,17 @@ __device__ __forceinline__ bool medium_root(const Tables& sc, const float4* geo,
     const uint32_t cx = sc.med_xform[m];
     if (cx != RT_MED_XF_MIXED) {
         if (cx != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, cx), o, d);
-        if (!boundary_root<true>(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
-        if (t1 > t_cull) return false;
-        if (!boundary_root<true>(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
+        const uint2 rg = sc.med_range[m];
+        const uint32_t kind = rg.y >> 24;
+        if (kind == RT_MED_KIND_RECTS) {
+            if (!boundary_both_rects(sc, geo, rg, o, d, t_cull, t1, t2)) return false;
+        } else if (kind == RT_MED_KIND_SPHERE) {
+            if (!boundary_both_sphere(sc, geo, rg, o, d, t_cull, t1, t2)) return false;
+        } else {
+            if (!boundary_root<true>(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
+            if (t1 > t_cull) return false;
+            if (!boundary_root<true>(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
+        }
     } else {
         if (!boundary_root<false>(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
         if (t1 > t_cull) return false;

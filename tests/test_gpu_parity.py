@@ -1228,6 +1228,39 @@ def test_hbm_resident_bvh_matches_lds(rt, renderer):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell_box", "final_scene", "random_1003", "random_1015", "random_1023", "random_1031", "random_1041", "random_1044"])
+def test_medium_boundary_one_evaluation_matches_two_searches(rt, renderer, name):
+    """ConstantMedium::hit (hitable.rs:541-552) searches its boundary twice; the kernels answer both searches from one
+    evaluation of the boundary where it is a box or a sphere (medium_root, rt_kernels.h).  Forcing the two searches the
+    reference makes must give the same bounce records and the same frame bit for bit."""
+    scene = _random_scene(rt, int(name[7:])) if name.startswith("random_") else rt.Scene.build(name, 1.0)
+    rng = np.random.default_rng(5)
+    n = 40000
+    lo, hi = (-12, 12) if name.startswith("random_") else (-100, 650)
+    o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[: n // 40, 1] = 0.0                                        # rays inside an axis plane: infinite / NaN plane distances
+    keys = rng.integers(0, 2**32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+    p = rt.make_params(160, 160, 8, max_depth=50)
+    out = []
+    for two_searches in (0, 1):
+        renderer.set_option("medium_search", two_searches)
+        try:
+            renderer.upload(scene)
+            g = renderer.debug_bounce(o, d, keys, depth=1)
+            img, _, st = renderer.render(scene.camera, p)
+        finally:
+            renderer.set_option("medium_search", 0)
+        out.append((g, img, int(st.n_rays)))
+    (g0, i0, n0), (g1, i1, n1) = out
+    n_prims = scene.flat.n_spheres + scene.flat.n_rects
+    assert scene.flat.n_media > 0 and (g0["hit"] >= n_prims).sum() > 20, "the scene's media are not reached"
+    for k in g0:
+        assert np.array_equal(g0[k].view(np.uint8), g1[k].view(np.uint8)), k
+    assert n0 == n1 and np.array_equal(i0.view(np.uint32), i1.view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_final_scene(rt, orc, renderer):
     """demo_scene.rs:150-221 — every hitable kind at once (instanced 1000-sphere cloud, 400 boxes, a sphere-bounded
     medium, image + Perlin textures, glass, fuzzy metal, BurleyDiffuse).  3.4 k primitives do not fit LDS, so this
