@@ -209,7 +209,10 @@ __global__ __launch_bounds__(256) void k_gen_primary(GenParams gp, Queue q) {
 // cone (axis, half-angle alpha given as sin/cos) against a bounding sphere seen from `origin`
 __device__ __forceinline__ bool cone_touches_sphere(V3 origin, V3 axis, float sa, float ca, float4 bs) {
     const V3 c = v3(bs.x, bs.y, bs.z) - origin;
-    const float r = bs.w * 1.001f + 1e-6f;
+    // (the last term: `c` is a difference of fp32 coordinates, good to half an ulp of the larger one per component — nothing next to
+    // the 0.1 % for a scene around the origin, the whole margin for a small sphere 1e5 units away from it)
+    const float big = fmaxf(fmaxf(fmaxf(fabsf(bs.x), fabsf(bs.y)), fabsf(bs.z)), fmaxf(fmaxf(fabsf(origin.x), fabsf(origin.y)), fabsf(origin.z)));
+    const float r = bs.w * 1.001f + 1e-6f + big * (1.0f / 2097152.0f);
     const float dist2 = length_squared(c);
     if (!(dist2 > r * r * 1.0001f)) return true; // the eye is inside or on the bounding sphere (or NaN)
     const float dist = sqrtf(dist2);
@@ -250,7 +253,18 @@ __global__ __launch_bounds__(256) void k_primary_lists(DevScene sc, GenParams gp
     smax = fmaxf(smax, length(cross(axis, normalize(llc + u1 * H + v0 * Vv - origin))));
     smax = fmaxf(smax, length(cross(axis, normalize(llc + u0 * H + v1 * Vv - origin))));
     smax = fmaxf(smax, length(cross(axis, normalize(llc + u1 * H + v1 * Vv - origin))));
-    const float alpha = asinf(fminf(smax, 1.0f)) * 1.02f + 1e-4f;
+    // The rays are what fp32 makes of camera.rs:43-46, and so are the four corners above: every component of
+    // llc + u H + v V - origin goes through four roundings of operands up to S = |llc| + |H| + |V| + |origin| (per component), so a
+    // sample's direction and each corner lie within e = 4 * 2^-23 * S of where exact arithmetic puts them, an angle of sqrt(3) e / |dir|
+    // each.  Nothing for a camera near the origin (1e-5 rad); for one 1e5 units away from it with the reference's unit focal length the
+    // directions are quantised to whole pixels (scripts/gpu_grid_fuzz.py, seed 494: a listed pixel lost a grazing sphere) — the
+    // cone then opens until the list overflows and the pixel's rays use the tree.
+    const V3 dc = llc + (0.5f * (u0 + u1)) * H + (0.5f * (v0 + v1)) * Vv - origin;
+    const float S = fmaxf(fmaxf(fabsf(llc.x) + fabsf(H.x) + fabsf(Vv.x) + fabsf(origin.x), fabsf(llc.y) + fabsf(H.y) + fabsf(Vv.y) + fabsf(origin.y)),
+                          fabsf(llc.z) + fabsf(H.z) + fabsf(Vv.z) + fabsf(origin.z));
+    const float rounding = 2.0f * 1.7321f * (S * (4.0f / 8388608.0f)) / (length(dc) * (1.0f - smax));
+    const float alpha = asinf(fminf(smax, 1.0f)) * 1.02f + 1e-4f + rounding;
+    const bool unusable = !(alpha < 1.5f); // (or NaN) no cone to speak of: the pixel's rays use the tree
     const float ca = cosf(alpha), sa = sinf(alpha);
 
     // ---- wave-level cull: one cone around the 64 pixels of the wave (any 64: a row strip, a row wrap, rows of
@@ -303,7 +317,7 @@ __global__ __launch_bounds__(256) void k_primary_lists(DevScene sc, GenParams gp
         }
     }
     if (!active) return;
-    const uint32_t head = n > RT_LIST_MAX ? RT_LIST_OVERFLOW : n;
+    const uint32_t head = (n > RT_LIST_MAX || unusable) ? RT_LIST_OVERFLOW : n;
     if (head == RT_LIST_OVERFLOW) atomicAdd(n_overflow, 1u);
     lists[pl] = make_uint4(head | (ids[0] << 16), ids[1] | (ids[2] << 16), ids[3] | (ids[4] << 16), ids[5] | (ids[6] << 16));
 }

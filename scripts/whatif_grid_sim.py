@@ -78,6 +78,9 @@ def simulate(o, d, c, r, g0, dims, cells, big, cell):
     n = len(o)
     steps = np.zeros(n, int)
     tests = np.zeros(n, int)
+    rep1 = np.zeros(n, int)   # tests of the sphere tested last (a one-entry mailbox would skip them)
+    rep2 = np.zeros(n, int)   # ... of one of the two tested last
+    repall = np.zeros(n, int) # ... of any sphere this ray has tested before
     g1 = g0 + dims * cell
     for i in range(n):
         oo, dd = o[i].astype(np.float64), d[i].astype(np.float64)
@@ -102,10 +105,17 @@ def simulate(o, d, c, r, g0, dims, cells, big, cell):
         with np.errstate(divide="ignore", invalid="ignore"):
             tmax = np.where(dd != 0, (nextp - oo) * inv, np.inf)
             tdel = np.where(dd != 0, cell * np.abs(inv), np.inf)
+        seen, last = set(), [-1, -1]
         while True:
             steps[i] += 1
             for s in cells.get((ix[0], ix[1], ix[2]), ()):
                 tests[i] += 1
+                rep1[i] += s == last[0]
+                rep2[i] += s in last
+                repall[i] += s in seen
+                seen.add(s)
+                if s != last[0]:
+                    last = [s, last[0]]
                 t, _ = sphere_t(oo, dd, c[s], r[s], tbest)
                 if t is not None:
                     tbest = t
@@ -116,6 +126,7 @@ def simulate(o, d, c, r, g0, dims, cells, big, cell):
             if ix[k] < 0 or ix[k] >= dims[k]:
                 break
             tmax[k] += tdel[k]
+    simulate.repeats = (rep1, rep2, repall)
     return steps, tests
 
 
@@ -156,6 +167,9 @@ def main():
               f"{len(big)} always-tested | per ray: {steps.mean():.2f} cells (p50 {np.median(steps):.0f}, p90 {np.percentile(steps, 90):.0f}, "
               f"max {steps.max()}), {tests.mean():.2f} sphere tests in cells (p90 {np.percentile(tests, 90):.0f}, max {tests.max()}) | "
               f"rays that never enter the grid {np.mean(steps == 0):.2f} | 64-ray blocks: mean/max steps {ws.mean() / max(ws.max(axis=1).mean(), 1e-9):.2f}")
+        r1, r2, ra = simulate.repeats
+        print(f"            repeated tests per ray (the same sphere listed in several cells of the ray's path): {ra.mean():.2f} of {tests.mean():.2f}; "
+              f"a mailbox of the sphere tested last would skip {r1.mean():.2f}, of the last two {r2.mean():.2f}")
 
 
 if __name__ == "__main__":

@@ -68,3 +68,33 @@ def path_keys(seed, pix, samp):
     k0 = fmix32((a + samp * 0x9E3779B9 + s_hi) & 0xFFFFFFFF)
     k1 = fmix32(((a ^ 0xA511E9B3) + samp * 0xC2B2AE3D) & 0xFFFFFFFF)
     return np.stack([k0, k1], axis=1).astype(np.uint32)
+
+
+def grid_fuzz_scene(rt, seed):
+    """The random sphere-only scene `seed` of scripts/gpu_grid_fuzz.py (16 to 3 000 spheres, equal or log-normal radii, a flat layer /
+    a cube / a thin slab, with and without huge spheres, at the origin or ~1e5 units from it, unit / tiny / large scale).
+    Returns the finished scene, the generator in the state the script continues from, and the parameters drawn."""
+    f = rt._ffi
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([16, 40, 150, 500, 1200, 3000]))
+    scale = float(rng.choice([1.0, 1.0, 1e-3, 250.0]))
+    shape = rng.choice(["layer", "cube", "slab"])
+    ext = {"layer": (10, 0.3, 10), "cube": (6, 6, 6), "slab": (12, 12, 0.5)}[shape]
+    centre = np.array([0.0, 0.0, 0.0]) if rng.random() < 0.7 else rng.normal(size=3) * 300.0
+    c = (rng.uniform(-1, 1, (n, 3)) * np.array(ext) + centre) * scale
+    rad = (np.full(n, 0.2) if rng.random() < 0.5 else np.exp(rng.normal(np.log(0.2), 0.5, n))) * scale
+    if rng.random() < 0.3:
+        rad[rng.integers(0, n, n // 10 + 1)] *= -1.0
+    s = rt.Scene.new()
+    mats = [s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.7, 0.6, 0.5))), s.material(f.MAT_METAL, color=(0.8, 0.8, 0.8), p=(0.1,)),
+            s.material(f.MAT_DIELECTRIC, p=(1.5,))]
+    n_huge = int(rng.choice([0, 1, 1, 2]))
+    for k in range(n_huge):  # a ground (and a second big sphere beside the cloud)
+        cc = (centre + (np.array([0.0, -ext[1] - 1000.0 - 0.3, 0.0]) if k == 0 else np.array([ext[0] + 1004.0, 0.0, 0.0]))) * scale
+        s.sphere(tuple(float(x) for x in cc), 1000.0 * scale, mats[0], "huge")
+    for ci, ri in zip(c, rad):
+        s.sphere(tuple(float(x) for x in ci), float(ri), mats[int(rng.integers(0, 3))], "s")
+    eye = (centre + np.array([0.3, 0.5, 2.2]) * max(ext)) * scale
+    s.set_camera(tuple(float(x) for x in eye), tuple(float(x) for x in centre * scale), (0, 1, 0), 50, 1.5)
+    s.finish()
+    return s, rng, n, scale, shape, ext, centre, c, rad, n_huge

@@ -691,8 +691,8 @@ def _compare_frames(orc, scene, p, img, ref, name, rt=None, renderer=None):
     if scene.flat.n_media or scene.flat.n_images:
         assert renderer is not None, "scenes with media or image textures need the renderer to re-trace their outliers"
         fin = fin & ~_explain_outliers(rt, orc, renderer, scene, p, img, it, name)[0][:, :, None]
-        if scene.flat.n_media:
-            ref = np.where(fin, ref, img)  # (the same pixels are set aside against the recursive order below)
+        ref = np.where(fin, ref, img)  # (the same pixels are set aside against the recursive order below: a neighbouring texel in a
+                                       # 96 x 64 frame is 2.6e-4 of RMSE on its own — random scene 1034 of scripts/gpu_random_scene_sweep.py)
     else:
         worst = np.abs(display(np.where(fin, img, 0)) - display(np.where(fin, it, 0))).max(initial=0.0)
         assert worst <= 1e-4, (name, worst)  # nothing to explain them with: no pixel may be off
@@ -1370,6 +1370,29 @@ def test_primary_candidate_lists_do_not_change_images(rt, renderer):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [494, 110, 205, 28, 206])
+def test_candidate_lists_of_a_camera_far_from_the_origin(rt, renderer, seed):
+    """camera.rs:43-46 in fp32 for a camera 1e5 units from the origin with the reference's unit focal length: `llc + u H + v V -
+    origin` is quantised to steps the size of a pixel, so a sample's ray can point outside the cone through the footprint's
+    corners.  k_primary_lists allows for the rounding (the cone opens, the list overflows, the pixel's rays use the tree):
+    lists == tree == list walk bit for bit.  The scenes are those of scripts/gpu_grid_fuzz.py with 500 spheres of scale 250
+    centred ~1e5 units out; seed 494 is the one that found it (a listed pixel had lost a grazing sphere 2 300 units away)."""
+    from helpers import grid_fuzz_scene
+    s, _, n, scale, _, _, centre, _, _, _ = grid_fuzz_scene(rt, seed)
+    assert n == 500 and scale == 250.0 and np.abs(centre).max() > 100.0
+    renderer.upload(s)
+    p = rt.make_params(96, 64, 4, max_depth=12, seed=seed)
+    a, _, sa = renderer.render(s.camera, p)
+    renderer.set_option("primary_lists", 1)
+    b, _, sb = renderer.render(s.camera, p)
+    renderer.set_option("primary_lists", 0)
+    c, _, sc = renderer.render(s.camera, rt.make_params(96, 64, 4, max_depth=12, seed=seed, flags=rt._ffi.FLAG_BRUTE_FORCE))
+    assert a.std() > 0.01
+    assert list(sa.rays_per_depth) == list(sb.rays_per_depth) == list(sc.rays_per_depth)
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32)) and np.array_equal(b.view(np.uint32), c.view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_depth0_closest_hit_launch_is_decided_inside_every_frame(rt):
     """Depth 0 of a sphere-only scene launches its closest-hit kernel only when some pixel's candidate list overflowed, and
     rt_render decides that inside the frame (the count k_primary_lists leaves is read back before anything else of the frame
@@ -1505,6 +1528,35 @@ def _random_scene(rt, seed):
     return s
 
 
+def _one_ulp_of_the_direction_moves_it_as_far(orc, renderer, scene, o, d, key, depth, what, dev, ref):
+    """Device and host evaluate the same fp32 expressions, but not with the same last bits everywhere (libm; the order a compiler
+    sums a dot product in registers is fixed, sin / cos / acos / atan2 / ln are not).  Where the reference's own formula cancels, one
+    such bit is amplified: smith_geo_ggx_aniso (pbr.rs:98-100) is 1 / (v.z + sqrt(.. + v.z^2)), and with v.z < 0 — a DisneyMetal
+    sphere below a RotateY wrapper whose face-normal quirk leaves n . i negative — the sum loses three digits (random scene 2546 of
+    scripts/gpu_random_scene_sweep.py, ray 20888: device 1.595165, host 1.595254, float64 1.595219; plain numpy float32 gives either,
+    depending on which way the direction's last bit is rounded).  No fixed tolerance covers that and still means something for the
+    well-conditioned materials, so a colour that differs by more than 5e-5 is accepted only if one of the two implementations' OWN
+    colour for this very ray moves at least a quarter as far when one component of the ray direction moves by one ulp (same draws):
+    then the difference is what a single rounding upstream does to this lobe."""
+    o6 = np.repeat(o[None], 6, axis=0)
+    k6 = np.repeat(key[None], 6, axis=0)
+    d6 = np.repeat(d[None], 6, axis=0)
+    for axis in range(3):
+        d6[2 * axis, axis] = np.nextafter(d[axis], np.float32(np.inf))
+        d6[2 * axis + 1, axis] = np.nextafter(d[axis], np.float32(-np.inf))
+    worst = 0.0
+    for res, base in ((orc.debug_bounce(scene.flat_ptr, o6, d6, k6, depth=depth, accel=orc.ACCEL_LIST), ref),
+                      (renderer.debug_bounce(o6, d6, k6, depth=depth), dev)):
+        q = res[what].astype(np.float64)
+        q = q[np.isfinite(q).all(axis=1)]
+        if len(q):
+            worst = max(worst, float(np.abs(q - base).max()))
+    ok = float(np.abs(dev - ref).max()) <= 4.0 * worst
+    if ok:
+        print(f"ill-conditioned {what}: device {dev.tolist()} host {ref.tolist()}, moves by {worst:.3g} under a one-ulp nudge of the direction (hit record at depth {depth})")
+    return ok
+
+
 @pytest.mark.parametrize("seed", list(range(48)))
 def test_random_scenes_bounce_parity(rt, orc, renderer, seed):
     """Seeded random scenes over every hitable / material / texture kind: tree search == list walk on the device bit for
@@ -1547,6 +1599,8 @@ def test_random_scenes_bounce_parity(rt, orc, renderer, seed):
             if med[r] and g["t"][r] != c["t"][r]:
                 continue  # a medium scatter whose t differs in the last bits (ln): the phase texture is evaluated an ulp away (hitable.rs:560-570)
             dist = _texel_edge_distance(scene, int(g["hit"][r]), o[r], d[r], g["t"][r])
+            if dist is None and _one_ulp_of_the_direction_moves_it_as_far(orc, renderer, scene, o[r], d[r], keys[r], depth, k, a_[r], c_[r]):
+                continue  # a formula that cancels (see there): one of the two moves that far itself when its input moves by one ulp
             assert dist is not None and dist <= 2.0, (k, "ray", int(r), "hit", int(g["hit"][r]), "colours differ away from a texel edge", dist, a_[r], c_[r])
     # and a small frame through the whole pipeline (queues, lists, media phase) against the oracle
     p = rt.make_params(96, 64, 4, max_depth=6)
