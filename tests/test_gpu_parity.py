@@ -1476,9 +1476,10 @@ def test_config2_full_size_three_searches_agree(rt, renderer):
     assert 2.5 < sa.n_rays / sa.n_paths < 2.6
 
 
-def _random_scene(rt, seed):
+def _random_scene(rt, seed, offset=None):
     """A seeded random scene through the piecewise API: spheres, rectangles and boxes, some below Translate / RotateY
-    wrappers, some bounding a ConstantMedium, with every material and texture kind."""
+    wrappers, some bounding a ConstantMedium, with every material and texture kind.  `offset`: the same scene moved there as a
+    whole — one more Translate around every object, and the camera (scripts/gpu_frame_fuzz.py: fp32 far from the origin)."""
     rng = np.random.default_rng(seed)
     f = rt._ffi
     s = rt.Scene.new()
@@ -1502,7 +1503,7 @@ def _random_scene(rt, seed):
                 h = s.translate(h, tuple(rng.uniform(-3, 3, 3)))
             else:
                 h = s.rotate_y(h, float(rng.uniform(-60, 60)))
-        return h
+        return h if offset is None else s.translate(h, tuple(float(x) for x in offset))
 
     for _ in range(int(rng.integers(3, 25))):
         wrap(s.sphere(tuple(rng.uniform(-8, 8, 3)), float(rng.uniform(0.3, 2.5)), material(True), "s"))
@@ -1523,7 +1524,8 @@ def _random_scene(rt, seed):
         s.constant_medium(wrap(b), float(rng.uniform(0.05, 1.5)), texs[int(rng.integers(3))])
     sky = int(rng.integers(3))
     s.set_sky(sky, "res/newport_loft.jpg" if sky == f.SKY_ENV else None)
-    s.set_camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 40, 1.5)
+    off = np.zeros(3) if offset is None else np.asarray(offset, dtype=np.float64)
+    s.set_camera(tuple(float(x) for x in off + np.array([13.0, 2.0, 3.0])), tuple(float(x) for x in off), (0, 1, 0), 40, 1.5)
     s.finish(use_bvh=bool(rng.integers(2)))
     return s
 
