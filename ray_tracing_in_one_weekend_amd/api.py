@@ -356,6 +356,18 @@ class Renderer:
             self._raise("rt_debug_bounce", rc)
         return out
 
+    def debug_shared_division(self, x, a):
+        """x / a element by element through the kernels' shared-reciprocal division (rt_debug_shared_division)."""
+        x = np.ascontiguousarray(x, dtype=np.float32).ravel()
+        a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+        assert x.shape == a.shape
+        out = np.zeros_like(x)
+        fp = lambda v: v.ctypes.data_as(C.POINTER(C.c_float))
+        rc = self._lib.rt_debug_shared_division(self._ctx, len(x), fp(x), fp(a), fp(out))
+        if rc != 0:
+            self._raise("rt_debug_shared_division", rc)
+        return out
+
     def deinterleave_bands(self, d_gathered, nx, ny, band, n_shards, d_out_f32=None, d_out_u8=None, stream=None):
         """rt_deinterleave_bands on device pointers (ints): gathered band buffers -> frame in image row order."""
         rc = self._lib.rt_deinterleave_bands(self._ctx, C.c_void_p(d_gathered), nx, ny, band, n_shards,

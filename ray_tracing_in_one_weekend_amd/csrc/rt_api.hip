@@ -1431,6 +1431,26 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
 
 } // extern "C"
 
+int rt_debug_shared_division(RtCtx* ctx, uint32_t n, const float* x, const float* a, float* out) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!x || !a || !out) return fail(ctx, RT_ERR_INVALID, "rt_debug_shared_division: NULL array");
+    if (n == 0) return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->dbg, (size_t)n * 3 * sizeof(float)))) return rc;
+    float* dx = (float*)ctx->dbg.p;
+    float* da = dx + n;
+    float* dq = da + n;
+    hipStream_t st = ctx->stream;
+    RT_HIP(ctx, hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    RT_HIP(ctx, hipMemcpyAsync(da, a, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_debug_shared_division, dim3((n + 255u) / 256u), dim3(256), 0, st, n, dx, da, dq);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipMemcpyAsync(out, dq, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipStreamSynchronize(st));
+    return RT_OK;
+}
+
 #ifdef RT_PROFILE_LANES
 // Diagnostic builds only (not declared in include/rtow_mi355x.h, absent from the product library): the lane statistics
 // of rt_kernels.h, optionally reset after reading.

@@ -471,6 +471,35 @@ __device__ __forceinline__ V3 world_to_local_with_rot(V3 norm, V3 tang0, V3 v, f
 }
 
 // ---------------------------------------------------------------------------------------------
+// x / a for many x and ONE a, correctly rounded.  What the compiler emits for an fp32 division on gfx9 is
+//     y = rcp(a'); y += y * (1 - a' y);  q = x' y;  q += (x' - a' q) y;  v_div_fmas(x' - a' q, y, q);  v_div_fixup
+// with a', x' = v_div_scale of the operands — powers of two that are 1 unless an exponent is extreme (a denormal or beyond 2^126,
+// a quotient denormal or beyond 2^96, a numerator below 2^-103).  Outside those cases the same fused multiply-adds on the unscaled
+// operands return the same bits, and the refined reciprocal `y` (a quarter-rate v_rcp and two fmas) depends on `a` alone: a ray's
+// |d|^2 divides the roots of every sphere it is tested against, a sphere's radius the three components of its normal.  Five
+// instructions and the fixup per quotient instead of eleven with a v_rcp.  v_div_fixup is the compiler's own last step: zeros keep
+// their sign, infinities and NaNs come out as IEEE wants them.  The extreme cases cannot carry a result here: a root below 2^-103 fails
+// `root < t_min` whatever its last bit, unit directions have a = 1 +- 1e-6, radii are ordinary numbers (rt_scene_upload rejects
+// non-finite geometry; a direction that is not unit is dropped by k_shade as main.rs:39 would panic).  Held by every bit-exact
+// comparison of t, o and d against the oracle's IEEE divisions, and against the list walk, which keeps the `/` operator.
+// ---------------------------------------------------------------------------------------------
+struct SharedRcp {
+    float a, y;
+};
+__device__ __forceinline__ SharedRcp shared_rcp(float a) {
+    const float y0 = __builtin_amdgcn_rcpf(a);
+    const float e = __builtin_fmaf(-a, y0, 1.0f);
+    return SharedRcp{a, __builtin_fmaf(e, y0, y0)};
+}
+__device__ __forceinline__ float div_shared(float x, const SharedRcp& r) {
+    float q = x * r.y;
+    float e = __builtin_fmaf(-r.a, q, x);
+    q = __builtin_fmaf(e, r.y, q);
+    e = __builtin_fmaf(-r.a, q, x);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(e, r.y, q), r.a, x);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Closest hit against one sphere (hitable.rs:75-91).  Returns the accepted root in `t_hit`.
 // The caller keeps (t, index) only; the HitRecord fields (hitable.rs:93-99) are derived
 // once for the final hit in shade().
@@ -493,6 +522,24 @@ __device__ __forceinline__ bool sphere_root(float4 g, V3 o, V3 d, float a, float
     float root = (-half_b - sqrtd) / a;
     if (root < t_min || t_max < root) {
         root = (-half_b + sqrtd) / a;
+        if (root < t_min || t_max < root) return false;
+    }
+    t_hit = root;
+    return true;
+}
+
+// The same with the divisions by a = |d|^2 through the ray's shared reciprocal (above); t_min > 0 only.
+__device__ __forceinline__ bool sphere_root(float4 g, V3 o, V3 d, const SharedRcp& ra, float t_min, float t_max, float& t_hit) {
+    V3 oc = o - v3(g.x, g.y, g.z);
+    float half_b = dot(oc, d);
+    float c = length_squared(oc) - g.w * g.w;
+    if (half_b > 0.0f && c > 0.0f) return false;
+    float discriminant = half_b * half_b - ra.a * c;
+    if (discriminant < 0.0f) return false;
+    float sqrtd = sqrtf(discriminant);
+    float root = div_shared(-half_b - sqrtd, ra);
+    if (root < t_min || t_max < root) {
+        root = div_shared(-half_b + sqrtd, ra);
         if (root < t_min || t_max < root) return false;
     }
     t_hit = root;
@@ -624,7 +671,9 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     } else if (is_medium) {
         on = v3(1.0f, 0.0f, 0.0f);                      // hitable.rs:574 rec.norm = Vec3A::X
     } else {
-        on = (p - v3(g.x, g.y, g.z)) / g.w;             // hitable.rs:95 outward_normal
+        const SharedRcp rr = shared_rcp(g.w);           // hitable.rs:95 outward_normal = (p - center) / radius, one reciprocal for three quotients
+        const V3 pc = p - v3(g.x, g.y, g.z);
+        on = v3(div_shared(pc.x, rr), div_shared(pc.y, rr), div_shared(pc.z, rr));
     }
     bool front_face = is_medium ? true : dot(rd, on) < 0.0f; // hitable.rs:26 / hitable.rs:575
     V3 n = front_face ? on : -on;                       // hitable.rs:27-31

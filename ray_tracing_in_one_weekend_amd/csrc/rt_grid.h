@@ -267,14 +267,15 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
     bool exhausted = false; // wave-uniform: the workgroup has no unclaimed rays left
     bool has = false;
     V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
-    float a = 1.0f, tbest = RT_FLT_MAX, texit = 0.0f;
+    SharedRcp rcp_a{1.0f, 1.0f}; // |d|^2 (hitable.rs:77) and its refined reciprocal: the divisor of every root of this ray
+    float tbest = RT_FLT_MAX, texit = 0.0f;
     float tmx = 0.f, tmy = 0.f, tmz = 0.f, tdx = 0.f, tdy = 0.f, tdz = 0.f;
     int hit = -1, cell = 0, sx = 1, sy = 1, sz = 1;
     uint32_t cnt = 0u, off = 0u, budget = 0u;
     size_t pos = 0;
     auto test_sphere = [&](uint32_t s) {
         float th;
-        if (sphere_root(s_geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th) && (th < tbest || (th == tbest && (int)s > hit))) {
+        if (sphere_root(s_geo[s], o, d, rcp_a, 1e-3f, RT_FLT_MAX, th) && (th < tbest || (th == tbest && (int)s > hit))) {
             tbest = th;
             hit = (int)s;
         }
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
                 const float4 ra = qa[RT_QSTRIDE * pos], rb = qb[RT_QSTRIDE * pos];
                 o = v3(ra.x, ra.y, ra.z);
                 d = v3(rb.x, rb.y, rb.z);
-                a = length_squared(d); // hitable.rs:77
+                rcp_a = shared_rcp(length_squared(d));
                 tbest = RT_FLT_MAX;
                 hit = -1;
                 has = true;

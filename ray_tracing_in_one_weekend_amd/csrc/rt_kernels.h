@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                     RT_LANE_STAT(14, fused && n_list != RT_LIST_OVERFLOW); // waves at depth 0 / lanes with a candidate list
                     if (fused && n_list != RT_LIST_OVERFLOW) {
                         // leaf_test<false> over the listed entries: Sphere::hit roots (hitable.rs:75-91), order-independent accept
-                        const float a = length_squared(d);
+                        const SharedRcp ra = shared_rcp(length_squared(d));
                         float tbest = RT_FLT_MAX;
                         int hit = -1;
                         const uint32_t ids[RT_LIST_MAX] = {list.x >> 16, list.y & 0xFFFFu, list.y >> 16, list.z & 0xFFFFu,
@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                             float th;
                             const int s = (int)ids[t];
                             if (t < n_list) RT_LANE_STAT(12, true); // (profiling builds: trips of the list test and lanes in them)
-                            if (t < n_list && sphere_root(s_geo[s], o, d, a, 1e-3f, RT_FLT_MAX, th) &&
+                            if (t < n_list && sphere_root(s_geo[s], o, d, ra, 1e-3f, RT_FLT_MAX, th) &&
                                 (th < tbest || (th == tbest && s > hit))) {
                                 tbest = th;
                                 hit = s;
@@ -1464,6 +1464,13 @@ __global__ __launch_bounds__(256) void k_debug_fill(GenParams gp, Queue q, const
     q.c[pos] = make_float2(1.0f, 1.0f);
 }
 
+
+// Test hook (rt_debug_shared_division): div_shared as the kernels use it.
+__global__ __launch_bounds__(256) void k_debug_shared_division(uint32_t n, const float* __restrict__ x, const float* __restrict__ a,
+                                                               float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = div_shared(x[i], shared_rcp(a[i]));
+}
 
 // Test hook: one bounce for caller-given rays, no queues (rt_debug_bounce).
 template <int BLOCK, bool USE_BVH, bool LDS_NODES>

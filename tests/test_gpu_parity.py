@@ -684,7 +684,7 @@ def _compare_frames(orc, scene, p, img, ref, name, rt=None, renderer=None):
     2e-5 RMSE with no pixel off by more than 1e-4 — in a scene with media or image textures every pixel beyond that is first
     re-traced and explained (_explain_outliers), in any other scene there is none; against the reference's recursive order an
     overflow can strike at a different factor of the chain, so there only the pixels finite in both are compared (RMSE_TOL)
-    and the two masks may differ in a 1e-4 fraction of the pixels at most."""
+    and the two masks may differ in a 1e-4 fraction of the pixels (one pixel of a small frame) at most."""
     it, _, _ = orc.render(scene.flat_ptr, scene.camera, p, orc.options(rng_mode=orc.RNG_COUNTER, estimator=orc.EST_ITERATIVE, accel=_accel_for(orc, scene)))
     assert np.array_equal(np.isfinite(img), np.isfinite(it)), name
     fin = np.isfinite(it)
@@ -699,7 +699,9 @@ def _compare_frames(orc, scene, p, img, ref, name, rt=None, renderer=None):
     e_it = rmse_display(np.where(fin, img, 0), np.where(fin, it, 0))
     assert e_it <= 2e-5, (name, e_it)
     both = np.isfinite(ref) & np.isfinite(img)
-    assert (np.isfinite(ref) != np.isfinite(img)).mean() <= 1e-4, name
+    # (one pixel of a 96 x 64 frame is 1.6e-4 of it: random scene 8937 of scripts/gpu_random_scene_sweep.py — the masks are identical
+    # against the iterative order above; the recursive order overflows one factor later in one path)
+    assert (np.isfinite(ref) != np.isfinite(img)).any(axis=2).sum() <= max(1, int(1e-4 * ref.shape[0] * ref.shape[1])), name
     e = rmse_display(np.where(both, img, 0), np.where(both, ref, 0))
     assert e <= RMSE_TOL, (name, e)
 
@@ -1207,6 +1209,62 @@ def test_constant_medium_and_cornell_box(rt, orc, renderer):
     parts = [renderer.render(scene.camera, rt.make_params(200, 200, 16, max_depth=50, shard_band=8, shard_count=2, shard_id=r, spp_slice=5))[0]
              for r in range(2)]
     assert np.array_equal(shard.deinterleave(parts, 200, 8, 2).view(np.uint32), img.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_shared_reciprocal_division_is_ieee_division(rt, renderer):
+    """csrc/rt_device.h div_shared: the roots of a ray are divided by |d|^2 (hitable.rs:85-89) and the components of a sphere's
+    normal by its radius (hitable.rs:95) with the compiler's own fp32 division sequence, the refined reciprocal of the divisor
+    computed once and the operand scaling left out.  Bit for bit IEEE division (numpy float32) wherever the hardware's
+    v_div_scale would not have scaled — a normal divisor below 2^126, a numerator of at least 2^-103 (or zero, infinite, NaN),
+    a quotient between 2^-126 and 2^96 — which covers every quotient a kernel can take a result from: unit directions, radii of
+    ordinary size, roots that have to pass `t >= 1e-3`.  Outside that range (mapped in the last block; no kernel divides there) it is wrong."""
+    f = np.float32
+    rng = np.random.default_rng(7)
+    n = 3_000_000
+
+    def bits_equal(q, ref):
+        both_nan = np.isnan(q) & np.isnan(ref)
+        return (q.view(np.uint32) == ref.view(np.uint32)) | both_nan
+
+    def pow2(lo, hi, size):  # random sign, exponent in [lo, hi), mantissa uniform
+        return (rng.choice([-1.0, 1.0], size) * rng.uniform(1.0, 2.0, size) * 2.0 ** rng.integers(lo, hi, size)).astype(f)
+
+    with np.errstate(all="ignore"):
+        # (1) the divisor of a ray's roots, |d|^2 of a unit direction; numerators of any size the discriminant can produce
+        a = (1.0 + rng.uniform(-3e-6, 3e-6, n)).astype(f)
+        x = pow2(-100, 100, n)
+        assert bits_equal(renderer.debug_shared_division(x, a), x / a).all()
+        # (2) the divisor of a normal: a radius (either sign), numerators p - c down to an ulp of a coordinate and exactly zero
+        a = pow2(-20, 20, n)
+        x = pow2(-60, 30, n)
+        x[: n // 100] = 0.0
+        x[n // 100: n // 50] = -0.0
+        assert bits_equal(renderer.debug_shared_division(x, a), x / a).all()
+        # (3) the whole range the sequence is exact on, exponents at random
+        ea = rng.integers(-120, 126, n)
+        ex = np.clip(ea + rng.integers(-124, 95, n), -102, 126)
+        keep = (ex - ea > -125) & (ex - ea < 95)
+        a = (rng.choice([-1.0, 1.0], n) * rng.uniform(1.0, 2.0, n) * 2.0 ** ea).astype(f)[keep]
+        x = (rng.choice([-1.0, 1.0], n) * rng.uniform(1.0, 2.0, n) * 2.0 ** ex).astype(f)[keep]
+        q, ref = renderer.debug_shared_division(x, a), x / a
+        ok = bits_equal(q, ref) | ~np.isfinite(ref) | (np.abs(ref) < f(2.0 ** -126))  # (a quotient that rounds into the edges)
+        assert ok.all(), (int((~ok).sum()), x[~ok][:4], a[~ok][:4], q[~ok][:4], ref[~ok][:4])
+        # (4) the special values v_div_fixup takes care of, against every kind of divisor
+        sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -3.5, 1e-30, 3e38], dtype=f)
+        x, a = (v.ravel() for v in np.meshgrid(sp, np.concatenate([sp[:-1], np.array([1e30], dtype=f)])))  # (a divisor of 3e38 is case 5)
+        q, ref = renderer.debug_shared_division(x, a), x / a
+        assert bits_equal(q, ref).all(), (x[~bits_equal(q, ref)], a[~bits_equal(q, ref)], q[~bits_equal(q, ref)], ref[~bits_equal(q, ref)])
+        # (5) every pair of exponents: it differs from IEEE ONLY where the hardware would have scaled its operands (no kernel divides there)
+        a = pow2(-149, 128, n)
+        x = pow2(-149, 128, n)
+        q, ref = renderer.debug_shared_division(x, a), x / a
+        ea, ex = np.frexp(a)[1] - 1, np.frexp(x)[1] - 1  # |v| = m 2^e, 1 <= m < 2
+        scaled = (ea < -126) | (ea >= 126) | (ex < -103) | (ex - ea >= 95) | (ex - ea <= -125)
+        differ = ~bits_equal(q, ref)
+        print(f"all exponents: {int(differ.sum())} of {n} random pairs differ from IEEE, all of them among the {int(scaled.sum())} with a denormal "
+              f"or >= 2^126 divisor, a numerator below 2^-103 or a quotient beyond 2^95 / below 2^-125")
+        assert not (differ & ~scaled).any(), (x[differ & ~scaled][:4], a[differ & ~scaled][:4])
 
 
 @pytest.mark.gpu
