@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 9u /* 9: RT_OPT_MEDIUM_SEARCH, rt_debug_shared_division (additions; every v8 layout and prototype unchanged) */
+#define RT_ABI_VERSION 9u /* 9: RT_OPT_MEDIUM_SEARCH, rt_debug_arithmetic (additions; every v8 layout and prototype unchanged) */
 
 /* error codes */
 #define RT_OK 0
@@ -444,12 +444,17 @@ typedef struct RtBounceIO {
 } RtBounceIO;
 int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io);
 
-/* Test hook for the one arithmetic routine of the kernels that is not an IEEE operator: out[i] = x[i] / a[i] as the kernels
- * compute the roots of a ray (divisor |d|^2, hitable.rs:85-89) and the normal of a sphere (divisor r, hitable.rs:95) — the
- * compiler's own fp32 division sequence with the refined reciprocal of the divisor shared between the quotients and without
- * the operand scaling that only extreme exponents need (csrc/rt_device.h, div_shared).  Host arrays of n floats.  The test holds
- * it against IEEE division bit for bit over the operand range the kernels can use it on, and maps where it may differ. */
-int rt_debug_shared_division(RtCtx* ctx, uint32_t n, const float* x, const float* a, float* out);
+/* Test hook for the two arithmetic routines of the kernels that are not the compiler's operators (csrc/rt_device.h; host arrays
+ * of n floats):
+ *   RT_ARITH_SHARED_DIVISION  out[i] = x[i] / a[i] as the kernels compute the roots of a ray (divisor |d|^2, hitable.rs:85-89) and
+ *       the normal of a sphere (divisor r, hitable.rs:95): the compiler's own fp32 division sequence with the refined reciprocal
+ *       of the divisor shared between the quotients and without the operand scaling that only extreme exponents need;
+ *   RT_ARITH_SQRT             out[i] = sqrt(x[i]) as the kernels take it of a discriminant and of a squared length: the compiler's
+ *       own sequence without the scaling of arguments below 2^-96 (`a` is not read).
+ * The test holds both against IEEE bit for bit over the operand range the kernels use them on, and maps where they may differ. */
+#define RT_ARITH_SHARED_DIVISION 0u
+#define RT_ARITH_SQRT 1u
+int rt_debug_arithmetic(RtCtx* ctx, uint32_t op, uint32_t n, const float* x, const float* a, float* out);
 
 #ifdef __cplusplus
 }

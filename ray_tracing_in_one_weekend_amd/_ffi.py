@@ -121,7 +121,7 @@ class RtSceneInfo(C.Structure):
 
 EXPECTED_ABI = 9  # RT_ABI_VERSION the struct layouts and prototypes below were written for
 GPU_SYMBOLS = ["rt_abi_version", "rt_build_id", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
-               "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce", "rt_debug_shared_division",
+               "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce", "rt_debug_arithmetic",
                "rt_get_depth_timings", "rt_set_progress", "rt_host_alloc", "rt_host_free", "rt_debug_set_option", "rt_debug_get_option",
                "rt_debug_scene_info", "rt_debug_grid_build", "rt_multi_create", "rt_multi_create_ex", "rt_multi_destroy", "rt_multi_device_count",
                "rt_multi_last_error", "rt_multi_scene_upload", "rt_multi_render", "rt_deinterleave_bands"]
@@ -174,8 +174,8 @@ def load_gpu_library():
     lib.rt_get_depth_timings.restype = C.c_int
     lib.rt_debug_bounce.argtypes = [vp, C.POINTER(RtBounceIO)]
     lib.rt_debug_bounce.restype = C.c_int
-    lib.rt_debug_shared_division.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    lib.rt_debug_shared_division.restype = C.c_int
+    lib.rt_debug_arithmetic.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.rt_debug_arithmetic.restype = C.c_int
     lib.rt_set_progress.argtypes = [vp, RtProgressFn, vp]
     lib.rt_set_progress.restype = C.c_int
     lib.rt_host_alloc.argtypes = [C.c_size_t]

@@ -357,15 +357,22 @@ class Renderer:
         return out
 
     def debug_shared_division(self, x, a):
-        """x / a element by element through the kernels' shared-reciprocal division (rt_debug_shared_division)."""
+        """x / a element by element through the kernels' shared-reciprocal division (rt_debug_arithmetic)."""
+        return self._debug_arithmetic(0, x, a)
+
+    def debug_sqrt(self, x):
+        """sqrt(x) element by element as the kernels take it of discriminants and squared lengths (rt_debug_arithmetic)."""
+        return self._debug_arithmetic(1, x, None)
+
+    def _debug_arithmetic(self, op, x, a):
         x = np.ascontiguousarray(x, dtype=np.float32).ravel()
-        a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+        a = x if a is None else np.ascontiguousarray(a, dtype=np.float32).ravel()
         assert x.shape == a.shape
         out = np.zeros_like(x)
         fp = lambda v: v.ctypes.data_as(C.POINTER(C.c_float))
-        rc = self._lib.rt_debug_shared_division(self._ctx, len(x), fp(x), fp(a), fp(out))
+        rc = self._lib.rt_debug_arithmetic(self._ctx, op, len(x), fp(x), fp(a), fp(out))
         if rc != 0:
-            self._raise("rt_debug_shared_division", rc)
+            self._raise("rt_debug_arithmetic", rc)
         return out
 
     def deinterleave_bands(self, d_gathered, nx, ny, band, n_shards, d_out_f32=None, d_out_u8=None, stream=None):

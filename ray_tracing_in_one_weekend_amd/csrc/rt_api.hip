@@ -1431,9 +1431,10 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
 
 } // extern "C"
 
-int rt_debug_shared_division(RtCtx* ctx, uint32_t n, const float* x, const float* a, float* out) {
+int rt_debug_arithmetic(RtCtx* ctx, uint32_t op, uint32_t n, const float* x, const float* a, float* out) {
     if (!ctx) return RT_ERR_INVALID;
-    if (!x || !a || !out) return fail(ctx, RT_ERR_INVALID, "rt_debug_shared_division: NULL array");
+    if (op > RT_ARITH_SQRT) return fail(ctx, RT_ERR_INVALID, "rt_debug_arithmetic: unknown operation");
+    if (!x || !out || (op == RT_ARITH_SHARED_DIVISION && !a)) return fail(ctx, RT_ERR_INVALID, "rt_debug_arithmetic: NULL array");
     if (n == 0) return RT_OK;
     RT_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
@@ -1443,8 +1444,8 @@ int rt_debug_shared_division(RtCtx* ctx, uint32_t n, const float* x, const float
     float* dq = da + n;
     hipStream_t st = ctx->stream;
     RT_HIP(ctx, hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    RT_HIP(ctx, hipMemcpyAsync(da, a, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_debug_shared_division, dim3((n + 255u) / 256u), dim3(256), 0, st, n, dx, da, dq);
+    if (op == RT_ARITH_SHARED_DIVISION) RT_HIP(ctx, hipMemcpyAsync(da, a, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_debug_arithmetic, dim3((n + 255u) / 256u), dim3(256), 0, st, op, n, dx, da, dq);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipMemcpyAsync(out, dq, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipStreamSynchronize(st));

@@ -33,9 +33,61 @@ __device__ __forceinline__ V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 // glam dot3: (x*x' + y*y') + z*z'
 __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ float length_squared(V3 a) { return dot(a, a); }
-__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
+// ---------------------------------------------------------------------------------------------
+// x / a for many x and ONE a, correctly rounded.  What the compiler emits for an fp32 division on gfx9 is
+//     y = rcp(a'); y += y * (1 - a' y);  q = x' y;  q += (x' - a' q) y;  v_div_fmas(x' - a' q, y, q);  v_div_fixup
+// with a', x' = v_div_scale of the operands — powers of two that are 1 unless an exponent is extreme (a denormal or beyond 2^126,
+// a quotient denormal or beyond 2^96, a numerator below 2^-103).  Outside those cases the same fused multiply-adds on the unscaled
+// operands return the same bits, and the refined reciprocal `y` (a quarter-rate v_rcp and two fmas) depends on `a` alone: a ray's
+// |d|^2 divides the roots of every sphere it is tested against, a sphere's radius the three components of its normal.  Five
+// instructions and the fixup per quotient instead of eleven with a v_rcp.  v_div_fixup is the compiler's own last step: zeros keep
+// their sign, infinities and NaNs come out as IEEE wants them.  The extreme cases cannot carry a result here: a root below 2^-103 fails
+// `root < t_min` whatever its last bit, unit directions have a = 1 +- 1e-6, radii are ordinary numbers (rt_scene_upload rejects
+// non-finite geometry; a direction that is not unit is dropped by k_shade as main.rs:39 would panic).  Held by every bit-exact
+// comparison of t, o and d against the oracle's IEEE divisions, and against the list walk, which keeps the `/` operator.
+// ---------------------------------------------------------------------------------------------
+struct SharedRcp {
+    float a, y;
+};
+__device__ __forceinline__ SharedRcp shared_rcp(float a) {
+    const float y0 = __builtin_amdgcn_rcpf(a);
+    const float e = __builtin_fmaf(-a, y0, 1.0f);
+    return SharedRcp{a, __builtin_fmaf(e, y0, y0)};
+}
+__device__ __forceinline__ float div_shared(float x, const SharedRcp& r) {
+    float q = x * r.y;
+    float e = __builtin_fmaf(-r.a, q, x);
+    q = __builtin_fmaf(e, r.y, q);
+    e = __builtin_fmaf(-r.a, q, x);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(e, r.y, q), r.a, x);
+}
+
+// sqrt(x), correctly rounded, as the compiler emits it for fp32 — v_sqrt_f32 (one ulp), then the neighbours s -+ 1 ulp tried with
+// two exact residuals x - s' s, then zeros and +inf passed through — without the 2^32 scaling it wraps around that for arguments
+// below 2^-96 (where the residuals would be denormal): 11 instructions instead of 16, two compare + select pairs (4 cycles each) fewer.
+// The same bits for every argument from 2^-96 up, for 0, inf, NaN and negative numbers.  Used where the argument cannot lie in
+// (0, 2^-96): a discriminant hb^2 - a c is a difference of two rounded numbers, zero or at least an ulp of them; the squared length
+// of a direction, of a rejection sample (coordinates k 2^-23) or of a sum / difference of unit vectors is zero or at least 2^-50.
+// Cross products (a tangent at a sphere's pole) keep sqrtf.  Held bit for bit against numpy by rt_debug_arithmetic's test, and by
+// every comparison of t, o and d with the oracle.
+__device__ __forceinline__ float sqrt_ns(float x) {
+#ifdef RT_SQRT_SCALED // (A/B builds, scripts/build_variant.py: the compiler's sequence with its scaling)
+    return sqrtf(x);
+#endif
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float r = 0.0f >= r_dn ? s_dn : s;
+    r = 0.0f < r_up ? s_up : r;
+    return __builtin_amdgcn_classf(x, 0x260) ? x : r; // -0, +0, +inf
+}
+__device__ __forceinline__ float length(V3 a) { return sqrt_ns(dot(a, a)); }
 // glam normalize: v * (1 / length)
 __device__ __forceinline__ V3 normalize(V3 a) {
+    float inv = 1.0f / sqrt_ns(dot(a, a)); // (the unscaled division sequence for this single quotient: no gain, ab12 of round 5)
+    return a * inv;
+}
+__device__ __forceinline__ V3 normalize_any(V3 a) { // (a vector whose squared length may be anything: sqrtf)
     float inv = 1.0f / sqrtf(dot(a, a));
     return a * inv;
 }
@@ -199,7 +251,16 @@ __device__ __forceinline__ float offset_axis(float p, float n) { // one lane of 
 __device__ __forceinline__ V3 offset_hit_point(V3 p, V3 n) { // math.rs:137-152
     return v3(offset_axis(p.x, n.x), offset_axis(p.y, n.y), offset_axis(p.z, n.z));
 }
-__device__ __forceinline__ bool near_one(V3 d) { return fabsf(length(d) - 1.0f) < 1e-6f; } // math.rs:13-15
+// math.rs:13-15: (v.length() - 1.0).abs() < 1e-6.  The square root is correctly rounded and monotone, s - 1 is exact near 1, so the
+// squared lengths that pass are an interval of floats: exactly the 50 from 0x3f7fffe0 (0.9999981) to 0x3f800011 (1.000002), found
+// by running the expression over every float (tests/test_device_constants.py does it again).  Two comparisons per ray instead of
+// a square root; NaN fails both ways.
+#define RT_NEAR_ONE_LO 0x3f7fffe0u
+#define RT_NEAR_ONE_HI 0x3f800011u
+__device__ __forceinline__ bool near_one(V3 d) {
+    const float l2 = dot(d, d);
+    return l2 >= __uint_as_float(RT_NEAR_ONE_LO) && l2 <= __uint_as_float(RT_NEAR_ONE_HI);
+}
 
 // hitable.rs:65-71 Sphere::get_uv
 __device__ __forceinline__ V2 sphere_get_uv(V3 n) {
@@ -471,35 +532,6 @@ __device__ __forceinline__ V3 world_to_local_with_rot(V3 norm, V3 tang0, V3 v, f
 }
 
 // ---------------------------------------------------------------------------------------------
-// x / a for many x and ONE a, correctly rounded.  What the compiler emits for an fp32 division on gfx9 is
-//     y = rcp(a'); y += y * (1 - a' y);  q = x' y;  q += (x' - a' q) y;  v_div_fmas(x' - a' q, y, q);  v_div_fixup
-// with a', x' = v_div_scale of the operands — powers of two that are 1 unless an exponent is extreme (a denormal or beyond 2^126,
-// a quotient denormal or beyond 2^96, a numerator below 2^-103).  Outside those cases the same fused multiply-adds on the unscaled
-// operands return the same bits, and the refined reciprocal `y` (a quarter-rate v_rcp and two fmas) depends on `a` alone: a ray's
-// |d|^2 divides the roots of every sphere it is tested against, a sphere's radius the three components of its normal.  Five
-// instructions and the fixup per quotient instead of eleven with a v_rcp.  v_div_fixup is the compiler's own last step: zeros keep
-// their sign, infinities and NaNs come out as IEEE wants them.  The extreme cases cannot carry a result here: a root below 2^-103 fails
-// `root < t_min` whatever its last bit, unit directions have a = 1 +- 1e-6, radii are ordinary numbers (rt_scene_upload rejects
-// non-finite geometry; a direction that is not unit is dropped by k_shade as main.rs:39 would panic).  Held by every bit-exact
-// comparison of t, o and d against the oracle's IEEE divisions, and against the list walk, which keeps the `/` operator.
-// ---------------------------------------------------------------------------------------------
-struct SharedRcp {
-    float a, y;
-};
-__device__ __forceinline__ SharedRcp shared_rcp(float a) {
-    const float y0 = __builtin_amdgcn_rcpf(a);
-    const float e = __builtin_fmaf(-a, y0, 1.0f);
-    return SharedRcp{a, __builtin_fmaf(e, y0, y0)};
-}
-__device__ __forceinline__ float div_shared(float x, const SharedRcp& r) {
-    float q = x * r.y;
-    float e = __builtin_fmaf(-r.a, q, x);
-    q = __builtin_fmaf(e, r.y, q);
-    e = __builtin_fmaf(-r.a, q, x);
-    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(e, r.y, q), r.a, x);
-}
-
-// ---------------------------------------------------------------------------------------------
 // Closest hit against one sphere (hitable.rs:75-91).  Returns the accepted root in `t_hit`.
 // The caller keeps (t, index) only; the HitRecord fields (hitable.rs:93-99) are derived
 // once for the final hit in shade().
@@ -518,7 +550,7 @@ __device__ __forceinline__ bool sphere_root(float4 g, V3 o, V3 d, float a, float
     if (t_min > 0.0f && half_b > 0.0f && c > 0.0f) return false;
     float discriminant = half_b * half_b - a * c;
     if (discriminant < 0.0f) return false;
-    float sqrtd = sqrtf(discriminant);
+    float sqrtd = sqrt_ns(discriminant);
     float root = (-half_b - sqrtd) / a;
     if (root < t_min || t_max < root) {
         root = (-half_b + sqrtd) / a;
@@ -536,7 +568,7 @@ __device__ __forceinline__ bool sphere_root(float4 g, V3 o, V3 d, const SharedRc
     if (half_b > 0.0f && c > 0.0f) return false;
     float discriminant = half_b * half_b - ra.a * c;
     if (discriminant < 0.0f) return false;
-    float sqrtd = sqrtf(discriminant);
+    float sqrtd = sqrt_ns(discriminant);
     float root = div_shared(-half_b - sqrtd, ra);
     if (root < t_min || t_max < root) {
         root = div_shared(-half_b + sqrtd, ra);
@@ -858,7 +890,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
             float ax = fmaxf(m.p0() * m.p0() / aspect, alpha_min);
             float ay = fmaxf(m.p0() * m.p0() * aspect, alpha_min);
             float rot = m.p2() * 2.0f * RT_PI;
-            V3 tang = normalize(cross(v3(0.0f, 1.0f, 0.0f), on)); // hitable.rs:96
+            V3 tang = normalize_any(cross(v3(0.0f, 1.0f, 0.0f), on)); // hitable.rs:96
             V3 h_local = world_to_local_with_rot(n, tang, h, rot);
             dm = gtr2_aniso(h_local, ax, ay);
             V3 i_local = world_to_local_with_rot(n, tang, -rd, rot);

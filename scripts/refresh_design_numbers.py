@@ -17,7 +17,7 @@ b2 = json.load(open(P + "bench_config2.json"))
 t2 = json.load(open(P + "traffic_config2.json")) if os.path.exists(P + "traffic_config2.json") else None
 v2 = json.load(open(P + "valu_config2.json"))["kernels"] if os.path.exists(P + "valu_config2.json") else None
 cb = b2["cpu_baseline"]
-block = (f"| round 5: the depth-0 launch decided inside the frame, two chains on two hardware queues, hit-record loads in one round trip (another box: ±2 %) | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
+block = (f"| round 5: the depth-0 launch decided inside the frame, two chains on two hardware queues, hit-record loads in one round trip, division / square root / `near_one` at the cost their operands need (another box: ±2 %) | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
          f"{100 * b2['roofline']['frac']:.1f} % |\n"
          f"| CPU oracle, stream order + BVH, {cb['cores']} host cores (EPYC 9575F), the faster of the portable and the `-march=native` build | "
          f"{cb['value']:.1f} | — | — |\n\n"
