@@ -71,9 +71,6 @@ __device__ __forceinline__ float div_shared(float x, const SharedRcp& r) {
 // Cross products (a tangent at a sphere's pole) keep sqrtf.  Held bit for bit against numpy by rt_debug_arithmetic's test, and by
 // every comparison of t, o and d with the oracle.
 __device__ __forceinline__ float sqrt_ns(float x) {
-#ifdef RT_SQRT_SCALED // (A/B builds, scripts/build_variant.py: the compiler's sequence with its scaling)
-    return sqrtf(x);
-#endif
     const float s = __builtin_amdgcn_sqrtf(x);
     const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
     const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
