@@ -444,16 +444,21 @@ typedef struct RtBounceIO {
 } RtBounceIO;
 int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io);
 
-/* Test hook for the two arithmetic routines of the kernels that are not the compiler's operators (csrc/rt_device.h; host arrays
+/* Test hook for the arithmetic routines of the kernels that are not the compiler's operators (csrc/rt_device.h; host arrays
  * of n floats):
  *   RT_ARITH_SHARED_DIVISION  out[i] = x[i] / a[i] as the kernels compute the roots of a ray (divisor |d|^2, hitable.rs:85-89) and
  *       the normal of a sphere (divisor r, hitable.rs:95): the compiler's own fp32 division sequence with the refined reciprocal
  *       of the divisor shared between the quotients and without the operand scaling that only extreme exponents need;
  *   RT_ARITH_SQRT             out[i] = sqrt(x[i]) as the kernels take it of a discriminant and of a squared length: the compiler's
- *       own sequence without the scaling of arguments below 2^-96 (`a` is not read).
- * The test holds both against IEEE bit for bit over the operand range the kernels use them on, and maps where they may differ. */
+ *       own sequence without the scaling of arguments below 2^-96 (`a` is not read);
+ *   RT_ARITH_TO_I32, _TO_U32  out[i] = the BITS of `x[i] as i32` / `x[i] as u32` with Rust's rule (toward zero, saturating, NaN -> 0;
+ *       math.rs:137-152 offset_hit_point, texture.rs:183-193): v_cvt_i32_f32 / v_cvt_u32_f32 (`a` is not read).
+ * The test holds the first two against IEEE bit for bit over the operand range the kernels use them on and maps where they may
+ * differ, the conversions against the Rust rule over every kind of argument. */
 #define RT_ARITH_SHARED_DIVISION 0u
 #define RT_ARITH_SQRT 1u
+#define RT_ARITH_TO_I32 2u
+#define RT_ARITH_TO_U32 3u
 int rt_debug_arithmetic(RtCtx* ctx, uint32_t op, uint32_t n, const float* x, const float* a, float* out);
 
 #ifdef __cplusplus

@@ -364,6 +364,14 @@ class Renderer:
         """sqrt(x) element by element as the kernels take it of discriminants and squared lengths (rt_debug_arithmetic)."""
         return self._debug_arithmetic(1, x, None)
 
+    def debug_to_i32(self, x):
+        """`x as i32` (Rust: toward zero, saturating, NaN -> 0) as the kernels convert (rt_debug_arithmetic)."""
+        return self._debug_arithmetic(2, x, None).view(np.int32)
+
+    def debug_to_u32(self, x):
+        """`x as u32` as the kernels convert (rt_debug_arithmetic)."""
+        return self._debug_arithmetic(3, x, None).view(np.uint32)
+
     def _debug_arithmetic(self, op, x, a):
         x = np.ascontiguousarray(x, dtype=np.float32).ravel()
         a = x if a is None else np.ascontiguousarray(a, dtype=np.float32).ravel()

@@ -1433,7 +1433,7 @@ int rt_debug_bounce(RtCtx* ctx, const RtBounceIO* io) {
 
 int rt_debug_arithmetic(RtCtx* ctx, uint32_t op, uint32_t n, const float* x, const float* a, float* out) {
     if (!ctx) return RT_ERR_INVALID;
-    if (op > RT_ARITH_SQRT) return fail(ctx, RT_ERR_INVALID, "rt_debug_arithmetic: unknown operation");
+    if (op > RT_ARITH_TO_U32) return fail(ctx, RT_ERR_INVALID, "rt_debug_arithmetic: unknown operation");
     if (!x || !out || (op == RT_ARITH_SHARED_DIVISION && !a)) return fail(ctx, RT_ERR_INVALID, "rt_debug_arithmetic: NULL array");
     if (n == 0) return RT_OK;
     RT_HIP(ctx, hipSetDevice(ctx->device));

@@ -109,17 +109,19 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) {
     if (x > hi) x = hi;
     return x;
 }
-// Rust `as u32`: saturating, NaN -> 0
+// Rust's `f as u32` / `f as i32`: toward zero, saturating, NaN -> 0 — which is what v_cvt_u32_f32 / v_cvt_i32_f32 do by themselves (CDNA ISA:
+// "out-of-range values saturate, NaN is converted to 0").  A C cast promises nothing outside the range, so written with compares it
+// compiled to three nested exec-mask regions per conversion (nine in offset_hit_point); the instruction is named instead.
+// tests/test_gpu_parity.py holds both against the Rust rule over every kind of argument (rt_debug_arithmetic).
 __device__ __forceinline__ uint32_t sat_u32(float f) {
-    if (!(f == f) || f <= 0.0f) return 0u;
-    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
-    return (uint32_t)f;
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
 }
 __device__ __forceinline__ int32_t sat_i32(float f) {
-    if (!(f == f)) return 0;
-    if (f <= -2147483648.0f) return (int32_t)0x80000000;
-    if (f >= 2147483648.0f) return 0x7FFFFFFF;
-    return (int32_t)f;
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
 }
 
 // Lane statistics (diagnostic builds only, -DRT_PROFILE_LANES; scripts/gpu_lane_stats.py): for each counted site,

@@ -1465,11 +1465,15 @@ __global__ __launch_bounds__(256) void k_debug_fill(GenParams gp, Queue q, const
 }
 
 
-// Test hook (rt_debug_arithmetic): div_shared and sqrt_ns as the kernels use them.
+// Test hook (rt_debug_arithmetic): div_shared, sqrt_ns and the saturating conversions as the kernels use them.
 __global__ __launch_bounds__(256) void k_debug_arithmetic(uint32_t op, uint32_t n, const float* __restrict__ x, const float* __restrict__ a,
                                                           float* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) out[i] = op == 0u ? div_shared(x[i], shared_rcp(a[i])) : sqrt_ns(x[i]);
+    if (i >= n) return;
+    if (op == 0u) out[i] = div_shared(x[i], shared_rcp(a[i]));
+    else if (op == 1u) out[i] = sqrt_ns(x[i]);
+    else if (op == 2u) out[i] = __int_as_float(sat_i32(x[i]));
+    else out[i] = __uint_as_float(sat_u32(x[i]));
 }
 
 // Test hook: one bounce for caller-given rays, no queues (rt_debug_bounce).

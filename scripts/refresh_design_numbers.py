@@ -40,7 +40,9 @@ if ff.get("first_frame_ms"):
     block += (f"What the reference's own timer covers — one frame per process (`main.rs:62-129`) — in a process of its own: `first_frame_ms` = {ff['first_frame_ms']:.0f} ms "
               f"(`rt_ctx_create` {pm['rt_ctx_create']:.0f}, host scene build {pm['scene_build_host']:.0f}, `rt_scene_upload` {pm['rt_scene_upload']:.0f}, first `rt_render` {pm['first_rt_render']:.0f} "
               f"of which {ff['first_render_device_ms']:.1f} ms on the device against {ff['second_render_device_ms']:.1f} for the second frame, {ff['first_render_trace_launches']} trace launches both), "
-              f"`alloc_bytes` = {ff['alloc_bytes'] / 1e9:.1f} GB.\n")
+              f"`alloc_bytes` = {ff['alloc_bytes'] / 1e9:.1f} GB.  (The first `rt_render` is 55-59 ms on a quiet box; when processes before it have just freed tens of GB "
+              f"its first `hipMalloc` waits for the driver — 0.5 s after the profile script's rocprofv3 runs, 3.9 s for the fifth fresh process in a row: "
+              f"`profiles/round5/first_frame_five_fresh_processes.txt`; the device time of the frame does not change.)\n")
 else:
     block += "\n"
 p = os.path.join(root, "DESIGN.md")

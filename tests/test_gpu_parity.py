@@ -1291,6 +1291,25 @@ def test_square_root_without_argument_scaling_is_ieee(rt, renderer):
 
 
 @pytest.mark.gpu
+def test_float_to_integer_conversions_follow_the_rust_rule(rt, renderer):
+    """`f as i32` / `f as u32` in Rust: toward zero, saturating at the ends of the range, NaN -> 0 (math.rs:137-152 converts
+    n * 256 for the origin offset, texture.rs:183-193 converts u * W for the texel index).  The kernels use v_cvt_i32_f32 /
+    v_cvt_u32_f32, which do exactly that by themselves; held here over every kind of argument."""
+    f = np.float32
+    rng = np.random.default_rng(3)
+    x = np.concatenate([
+        (rng.normal(size=2_000_000) * 10.0 ** rng.uniform(-3, 12, 2_000_000)).astype(f),
+        np.array([0.0, -0.0, 0.5, -0.5, 0.99999994, -0.99999994, 1.0, -1.0, 255.99, 256.0, -256.0, 2147483520.0, 2147483648.0, -2147483648.0,
+                  -2147483904.0, 4294967040.0, 4294967296.0, 1e20, -1e20, np.inf, -np.inf, np.nan, -np.nan, 1e-40, -1e-40], dtype=f)])
+    with np.errstate(all="ignore"):
+        t = np.trunc(np.where(np.isnan(x), 0.0, x).astype(np.float64))
+        want_i = np.clip(t, -2147483648.0, 2147483647.0).astype(np.int64).astype(np.int32)
+        want_u = np.clip(t, 0.0, 4294967295.0).astype(np.int64).astype(np.uint32)
+    assert np.array_equal(renderer.debug_to_i32(x), want_i)
+    assert np.array_equal(renderer.debug_to_u32(x), want_u)
+
+
+@pytest.mark.gpu
 def test_hbm_resident_bvh_matches_lds(rt, renderer):
     """Scenes whose tree exceeds LDS traverse it out of HBM/L2; forcing that path on sphere_scene must give the
     LDS path's frame bit for bit (same tree, same traversal order, same tie rule)."""
