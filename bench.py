@@ -240,14 +240,20 @@ def first_frame_child(cfg, nx, ny, spp, max_depth):
     params = rt.make_params(nx, ny, spp, max_depth=max_depth, seed=95)
     _, _, st1 = renderer.render(scene.camera, params, want_rgb8=True, pinned=True)
     t_f1 = time.perf_counter()
+    parts1 = renderer.render_parts()
     free1 = free_bytes()
     _, _, st2 = renderer.render(scene.camera, params, want_rgb8=True, pinned=True)
     t_f2 = time.perf_counter()
+    parts2 = renderer.render_parts()
     ms = lambda a, b: round((b - a) * 1e3, 2)
     print(json.dumps({
         "first_frame_ms": ms(t_rt, t_f1),  # rt_ctx_create + scene build + rt_scene_upload + first rt_render (f32 + RGB8 to the host)
         "parts_ms": {"hip_runtime_and_import": ms(t0, t_rt), "rt_ctx_create": ms(t_rt, t_ctx), "scene_build_host": ms(t_ctx, t_scene),
                      "rt_scene_upload": ms(t_scene, t_up), "first_rt_render": ms(t_up, t_f1), "second_rt_render": ms(t_f1, t_f2)},
+        # rt_debug_render_parts: where the host spent the first rt_render (allocations one by one, the first kernel launch = code
+        # object load + hardware-queue probe, the candidate lists with the one in-frame synchronisation, enqueue, wait)
+        "first_render_parts_ms": parts1, "second_render_parts_ms": parts2,
+        "first_render_slices": int(st1.n_slices), "second_render_slices": int(st2.n_slices),
         "first_render_device_ms": round(st1.seconds_device * 1e3, 3), "second_render_device_ms": round(st2.seconds_device * 1e3, 3),
         "first_render_trace_launches": int(st1.n_trace_launches), "second_render_trace_launches": int(st2.n_trace_launches),
         "alloc_bytes": (free0 - free1) if free0 is not None and free1 is not None else None,
@@ -437,12 +443,21 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(record) + "\n").encode())
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # The reference renders ONE frame per process (main.rs:62-129) and its timer covers scene build + render (utils.rs:15-18):
+    # that frame is measured in a child process, twice — here, BEFORE this process has imported torch or touched the GPU (a
+    # quiet device: nobody else holds or has just freed memory), and after the timed region while this process still holds its
+    # own work buffers (a device with a tenant).  The second is `first_frame`, the first `first_frame_quiet_device`.
+    ff_quiet = None
+    if world == 1 and not (args.timed_only or args.launcher_check):
+        c0 = CONFIGS[args.config or 2]
+        ff_quiet = first_frame(args.config or 2, args.nx or c0["nx"], args.ny or c0["ny"], args.spp or c0["spp"], args.max_depth)
+
+    import torch
+    import torch.distributed as dist
+
     if world != n_req:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(torchrun --nproc-per-node {n_req}, or let `python bench.py --gpus {n_req}` spawn them)")
@@ -638,6 +653,7 @@ def main():
             # every number above is a warm, steady-state frame; the reference renders ONE frame per process (main.rs:62-129)
             ff = first_frame(config_id, nx, ny, spp_total, args.max_depth)
             out["first_frame"] = ff
+            out["first_frame_quiet_device"] = ff_quiet
             out["first_frame_ms"] = ff.get("first_frame_ms")
             out["alloc_bytes"] = ff.get("alloc_bytes")
         if args.in_library or world > 1:

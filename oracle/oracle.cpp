@@ -27,7 +27,7 @@
  *   counter : the counter-based generator that the GPU uses, keyed by (pixel, sample) with a
  *             counter block per depth (DESIGN.md "RNG").  This is the parity oracle.
  */
-#include "../include/rtow_mi355x.h"
+#include "../include/rtow_mi355x_debug.h" /* RtBounceIO: the oracle mirrors the single-bounce test hook */
 
 #include <algorithm>
 #include <atomic>
@@ -753,8 +753,10 @@ float perlin_noise(const RtFlatScene& fs, uint32_t set, V3 p) { /* texture.rs:12
     for (int di = 0; di < 2; ++di)
         for (int dj = 0; dj < 2; ++dj)
             for (int dk = 0; dk < 2; ++dk) {
-                unsigned index = (unsigned)px[rem_euclid_256(i + di)] ^ (unsigned)py[rem_euclid_256(j + dj)] ^
-                                 (unsigned)pz[rem_euclid_256(k + dk)];
+                /* `i + di` on isize: wraps at isize::MAX in a release build (a debug build panics), so the sum is taken unsigned */
+                auto plus = [](int64_t a, int b) { return (int64_t)((uint64_t)a + (uint64_t)b); };
+                unsigned index = (unsigned)px[rem_euclid_256(plus(i, di))] ^ (unsigned)py[rem_euclid_256(plus(j, dj))] ^
+                                 (unsigned)pz[rem_euclid_256(plus(k, dk))];
                 c[di][dj][dk] = v3(rv[3 * index], rv[3 * index + 1], rv[3 * index + 2]);
             }
     V3 uvw = p - v3(std::floor(p.x), std::floor(p.y), std::floor(p.z));

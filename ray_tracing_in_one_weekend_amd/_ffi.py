@@ -1,4 +1,4 @@
-"""ctypes declarations of the two C ABIs (include/rtow_mi355x.h, include/rtow_host.h).
+"""ctypes declarations of the two C ABIs (include/rtow_mi355x.h + its test hooks in include/rtow_mi355x_debug.h, include/rtow_host.h).
 
 Plumbing only: struct layouts, library loading and argument types.  The GPU library is
 mandatory for rendering; `load_gpu_library()` raises if it is missing — there is no CPU
@@ -123,7 +123,7 @@ EXPECTED_ABI = 9  # RT_ABI_VERSION the struct layouts and prototypes below were 
 GPU_SYMBOLS = ["rt_abi_version", "rt_build_id", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
                "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce", "rt_debug_arithmetic",
                "rt_get_depth_timings", "rt_set_progress", "rt_host_alloc", "rt_host_free", "rt_debug_set_option", "rt_debug_get_option",
-               "rt_debug_scene_info", "rt_debug_grid_build", "rt_multi_create", "rt_multi_create_ex", "rt_multi_destroy", "rt_multi_device_count",
+               "rt_debug_scene_info", "rt_debug_grid_build", "rt_debug_render_parts", "rt_multi_create", "rt_multi_create_ex", "rt_multi_destroy", "rt_multi_device_count",
                "rt_multi_last_error", "rt_multi_scene_upload", "rt_multi_render", "rt_deinterleave_bands"]
 HOST_SYMBOLS = ["rth_last_error", "rth_register_image", "rth_rng_reseed", "rth_scene_build", "rth_scene_new",
                 "rth_tex_constant", "rth_tex_checker", "rth_tex_perlin", "rth_tex_image", "rth_material",
@@ -188,6 +188,8 @@ def load_gpu_library():
     lib.rt_debug_get_option.restype = C.c_int
     lib.rt_debug_scene_info.argtypes = [vp, C.POINTER(RtSceneInfo)]
     lib.rt_debug_scene_info.restype = C.c_int
+    lib.rt_debug_render_parts.argtypes = [vp, C.c_char_p, C.c_uint32]
+    lib.rt_debug_render_parts.restype = C.c_int
     lib.rt_debug_grid_build.argtypes = [C.POINTER(RtFlatScene), C.c_uint32, C.c_uint32, C.c_float * 8, C.c_uint32 * 3, _u32, _u32, _u16, _u32,
                                         C.c_uint32 * 4, _u32]
     lib.rt_debug_grid_build.restype = C.c_int

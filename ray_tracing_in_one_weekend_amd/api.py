@@ -323,6 +323,16 @@ class Renderer:
             self._raise("rt_render_device", rc)
         return stats
 
+    def render_parts(self):
+        """rt_debug_render_parts: host-side timeline of the last render as {label: ms} in call order (allocations one by one, the
+        hardware-queue probe = first kernel launch, candidate lists + the in-frame synchronisation, enqueue, wait)."""
+        import json
+        buf = C.create_string_buffer(4096)
+        n = self._lib.rt_debug_render_parts(self._ctx, buf, len(buf))
+        if n < 0:
+            self._raise("rt_debug_render_parts", n)
+        return json.loads(buf.value.decode())
+
     def depth_timings(self, max_n=128):
         """(isect_ms, shade_ms, rays) per depth of the first slice of the last render with FLAG_TIME_DEPTHS."""
         a = np.zeros(max_n, np.float32)

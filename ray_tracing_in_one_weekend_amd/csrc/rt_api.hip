@@ -1,7 +1,7 @@
 // rt_api.hip — implementation of the C-ABI in include/rtow_mi355x.h on top of the gfx950
 // wavefront kernels (rt_kernels.h).  One context = one GPU = one HIP stream; the bounce loop
 // of a slice is enqueued without any host synchronisation (queue sizes live in HBM).
-#include "../../include/rtow_mi355x.h"
+#include "../../include/rtow_mi355x_debug.h"
 #include "rt_kernels.h"
 #include "rt_bvh.h"
 #include "rt_grid.h"
@@ -72,6 +72,16 @@ struct RtCtx {
     bool progress_armed = false; // set by rt_render around render_impl, so rt_render_device stays callback-free
     DevBuf preview_u8;
     std::vector<uint8_t> preview_host;
+    // Host-side timeline of the last render_impl (rt_debug_render_parts): wall-clock milliseconds between marks.  The first
+    // render of a process is where allocations, code-object loads and the queue probe happen; this says which.
+    std::vector<std::pair<const char*, double>> parts;
+    std::chrono::steady_clock::time_point parts_t{};
+    void parts_begin() { parts.clear(), parts_t = std::chrono::steady_clock::now(); }
+    void mark(const char* what) {
+        const auto t = std::chrono::steady_clock::now();
+        parts.emplace_back(what, std::chrono::duration<double, std::milli>(t - parts_t).count());
+        parts_t = t;
+    }
 };
 
 namespace {
@@ -276,7 +286,9 @@ int ensure_queues(RtCtx* ctx, size_t n_rays) {
         int rc;
         if ((rc = ensure(ctx, ctx->qbuf[3 * k], RT_QSTRIDE * qbytes))) return rc;
         if (RT_QSTRIDE == 1u && (rc = ensure(ctx, ctx->qbuf[3 * k + 1], qbytes))) return rc;
+        ctx->mark(k ? "alloc_queue1_ab" : "alloc_queue0_ab");
         if ((rc = ensure(ctx, ctx->qbuf[3 * k + 2], qbytes / 2))) return rc;
+        ctx->mark(k ? "alloc_queue1_c" : "alloc_queue0_c");
     }
     return RT_OK;
 }
@@ -901,6 +913,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     RT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
     const auto wall0 = std::chrono::steady_clock::now();
+    ctx->parts_begin();
 
     const uint32_t nx = prm->nx, ny = prm->ny, spp = prm->spp;
     const uint32_t band = prm->shard_band ? prm->shard_band : 1u;
@@ -942,7 +955,9 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
 
     if ((rc = ensure_queues(ctx, (size_t)nq * cap))) return rc;
     if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
+    ctx->mark("alloc_hit_records");
     if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * RT_RAD_FLOATS * sizeof(float)))) return rc;
+    ctx->mark("alloc_radiance_slots");
     if ((rc = ensure(ctx, ctx->acc, (size_t)npix * 3 * sizeof(float)))) return rc;
     const size_t counts_bytes = (size_t)(n_depths + 1) * nq * sizeof(uint32_t); // queue sizes [depth][shard]
     if ((rc = ensure(ctx, ctx->counts, counts_bytes))) return rc;
@@ -961,9 +976,11 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     float* acc = (float*)ctx->acc.p;
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     unsigned long long* totals = (unsigned long long*)ctx->totals.p; // [0]=tex fetches [1]=bad dirs [2..]=rays per depth
+    ctx->mark("alloc_small_buffers_and_events");
 
     // (before the frame's own clock starts: once per launch stream, 0.3 ms of spin kernels; see ensure_concurrent_chains)
     if (nq >= 2u * RT_ISECT_MAX_SHARDS && (rc = ensure_concurrent_chains(ctx, st))) return rc;
+    ctx->mark("queue_probe"); // (the first kernel launch of a process: the code object is loaded here)
     RT_HIP(ctx, hipEventRecord(ctx->ev_begin, st));
     RT_HIP(ctx, hipMemsetAsync(acc, 0, (size_t)npix * 3 * sizeof(float), st));
     RT_HIP(ctx, hipMemsetAsync(totals, 0, totals_bytes, st));
@@ -1020,6 +1037,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             RT_HIP(ctx, hipStreamSynchronize(st));
             no_overflow = *ctx->h_overflow == 0u;
         }
+        ctx->mark("primary_lists_and_in_frame_sync");
     }
 
     uint32_t n_trace_launches = 0;
@@ -1123,6 +1141,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
                        (uint8_t*)d_out_rgb8, nx, rows, spp, gp.tiles_per_row, gp.tile_pixels);
     RT_HIP(ctx, hipEventRecord(ctx->ev_end, st));
     RT_HIP(ctx, hipGetLastError());
+    ctx->mark("enqueue_all_launches");
     // Device -> host.  A destination in pinned host memory (rt_host_alloc, or memory the caller registered with HIP) is written
     // by the copy engine at PCIe rate while this thread goes on; a pageable one makes hipMemcpyAsync stage and wait, as
     // hipMemcpy would (24.9 + 6.2 MB of a 1920 x 1080 frame: ~3 ms against ~0.6 ms).
@@ -1132,6 +1151,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
 
     if (stats) {
         RT_HIP(ctx, hipStreamSynchronize(st));
+        ctx->mark("wait_for_the_device");
         std::vector<unsigned long long> h((size_t)n_depths + 2);
         RT_HIP(ctx, hipMemcpy(h.data(), totals, totals_bytes, hipMemcpyDeviceToHost));
         std::memset(stats, 0, sizeof(*stats));
@@ -1208,6 +1228,23 @@ int rt_debug_set_option(RtCtx* ctx, uint32_t option, uint32_t value) {
     if (option >= RT_OPT__COUNT) return fail(ctx, RT_ERR_INVALID, "rt_debug_set_option: unknown option");
     ctx->opt[option] = value;
     return RT_OK;
+}
+
+int rt_debug_render_parts(const RtCtx* ctx, char* buf, uint32_t cap) {
+    if (!ctx) return RT_ERR_INVALID;
+    std::string js = "{";
+    char num[64];
+    for (size_t k = 0; k < ctx->parts.size(); ++k) {
+        std::snprintf(num, sizeof(num), "\": %.3f", ctx->parts[k].second);
+        js += (k ? ", \"" : "\"") + std::string(ctx->parts[k].first) + num;
+    }
+    js += "}";
+    if (buf && cap) {
+        const size_t n = std::min<size_t>(js.size(), cap - 1u);
+        std::memcpy(buf, js.data(), n);
+        buf[n] = 0;
+    }
+    return (int)js.size() + 1;
 }
 
 int rt_debug_get_option(const RtCtx* ctx, uint32_t option, uint32_t* value) {

@@ -359,13 +359,23 @@ struct PerlinTables {
     const float4* vec;   // [n_sets*256] xyz_
     const unsigned short* perm; // [n_sets*768] pairs of perm_x, perm_y, perm_z
 };
-__device__ inline float perlin_noise(const PerlinTables& pt, uint32_t set, V3 p) { // texture.rs:125-146, 93-112
+// Lattice index of a far coordinate.  The reference takes `p.x.floor() as isize` and `(i + di).rem_euclid(256)` (texture.rs:126-138):
+// a saturating conversion to 64 bits.  sat_i32 (v_cvt_i32_f32) followed by `& 255` is that for |fx| < 2^31 (two's complement), for
+// fx <= -2^31 (saturates to 0x80000000: index 0, as every float there is a multiple of 256 and isize::MIN is one too), for NaN (0)
+// and for fx >= 2^63 (0x7FFFFFFF: index 255 and, through the pair table, 0 for i + 1 — isize::MAX and the wrapped isize::MIN of a
+// release build; a debug build of the reference panics there).  It is NOT that for 2^31 <= fx < 2^63, multiples of 256 every one:
+// index 0.  perlin_turb tells its octaves whether any coordinate can get there (`far`), so the near path pays nothing.
+__device__ __forceinline__ int perlin_far_index(float fx, int i) {
+    return (fx >= 2147483648.0f && fx < 9223372036854775808.0f) ? 0 : i;
+}
+__device__ inline float perlin_noise(const PerlinTables& pt, uint32_t set, V3 p, bool far) { // texture.rs:125-146, 93-112
     const float4* rv = pt.vec + (size_t)set * 256;
     const unsigned short* px = pt.perm + (size_t)set * 768;
     const unsigned short* py = px + 256;
     const unsigned short* pz = py + 256;
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
-    int i = (int)fx, j = (int)fy, k = (int)fz;
+    int i = sat_i32(fx), j = sat_i32(fy), k = sat_i32(fz); // `as isize`: saturating, NaN -> 0
+    if (far) i = perlin_far_index(fx, i), j = perlin_far_index(fy, j), k = perlin_far_index(fz, k);
     V3 uvw = p - v3(fx, fy, fz);
     V3 uvw2 = uvw * uvw * (3.0f - 2.0f * uvw); // math.rs:133-135 smooth
     float u = uvw2.x, v = uvw2.y, w = uvw2.z;
@@ -396,8 +406,10 @@ __device__ inline float perlin_noise(const PerlinTables& pt, uint32_t set, V3 p)
 __device__ inline float perlin_turb(const PerlinTables& pt, uint32_t set, V3 p) { // texture.rs:115-124
     float accum = 0.0f;
     float w = 1.0f;
+    // 2^25: the seventh octave looks up p * 2^6 (a NaN coordinate is index 0 on either path)
+    const bool far = fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)) >= 33554432.0f;
     for (int it = 0; it < 7; ++it) {
-        accum += w * perlin_noise(pt, set, p);
+        accum += w * perlin_noise(pt, set, p, far);
         p = p * 2.0f;
         w *= 0.5f;
     }

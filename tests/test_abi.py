@@ -18,9 +18,16 @@ def _declared_functions(header):
     return sorted(set(names))
 
 
+PRODUCT_HEADER, DEBUG_HEADER = "rtow_mi355x.h", "rtow_mi355x_debug.h"
+
+
 def test_gpu_library_exports_every_declared_symbol(rt):
     lib = rt._ffi.load_gpu_library()
-    names = _declared_functions("rtow_mi355x.h")
+    product, hooks = _declared_functions(PRODUCT_HEADER), _declared_functions(DEBUG_HEADER)
+    # the header a host binds holds lifecycle / scene / render / multi-GPU / progress and no test hook
+    assert product and not [n for n in product if "debug" in n or n == "rt_get_depth_timings"], product
+    assert hooks and not set(product) & set(hooks)
+    names = sorted(product + hooks)
     assert set(names) == set(rt._ffi.GPU_SYMBOLS), (names, rt._ffi.GPU_SYMBOLS)
     for n in names:
         assert hasattr(lib, n), n
@@ -42,7 +49,7 @@ def test_host_library_exports_every_declared_symbol(rt):
 
 def test_struct_layouts_match_the_c_compiler(rt, tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rtow_mi355x.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rtow_mi355x_debug.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(RtFlatScene),sizeof(RtCamera),sizeof(RtParams),sizeof(RtStats),sizeof(RtBounceIO),'
                    'offsetof(RtFlatScene,sky_type),offsetof(RtStats,rays_per_depth),offsetof(RtParams,seed));return 0;}\n')
     exe = tmp_path / "sz"
@@ -52,6 +59,136 @@ def test_struct_layouts_match_the_c_compiler(rt, tmp_path):
     want = [C.sizeof(f.RtFlatScene), C.sizeof(f.RtCamera), C.sizeof(f.RtParams), C.sizeof(f.RtStats), C.sizeof(f.RtBounceIO),
             f.RtFlatScene.sky_type.offset, f.RtStats.rays_per_depth.offset, f.RtParams.seed.offset]
     assert got == want
+
+
+# ---- the Rust binding text of INTEGRATION.md section 1 against the headers -----------------------------------------------
+_C2RUST = {"uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64", "int32_t": "i32", "int": "i32", "float": "f32", "double": "f64",
+           "size_t": "usize", "char": "c_char", "void": "c_void"}
+
+
+def _strip_c(src):
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef RT_PROFILE_LANES.*?#endif", "", src, flags=re.S)
+    return src
+
+
+def _c_type_to_rust(ctype, array=None):
+    """'const float*' -> '*const f32', 'RtCtx**' -> '*mut *mut RtCtx', 'float' + [3] -> '[f32; 3]' (a parameter array decays)."""
+    t = ctype.strip()
+    stars = t.count("*")
+    t = t.replace("*", " ").split()
+    const = "const" in t
+    base = [w for w in t if w not in ("const", "struct")]
+    assert len(base) == 1, ctype
+    r = _C2RUST.get(base[0], base[0])
+    for k in range(stars):
+        r = ("*const " if (const and k == 0) else "*mut ") + r
+    return f"[{r}; {array}]" if array else r
+
+
+def _c_structs(header):
+    out = {}
+    for body, name in re.findall(r"typedef struct \w+ \{(.*?)\}\s*(\w+);", _strip_c(open(os.path.join(ROOT, "include", header)).read()), flags=re.S):
+        fields = []
+        for decl in [d.strip() for d in body.split(";") if d.strip()]:
+            m = re.match(r"(.*?[\s\*])(\w+(?:\s*,\s*\w+)*)\s*(?:\[(\d+)\])?$", decl, flags=re.S)
+            assert m, decl
+            for fname in [x.strip() for x in m.group(2).split(",")]:
+                fields.append((fname, _c_type_to_rust(m.group(1), m.group(3))))
+        out[name] = fields
+    return out
+
+
+def _c_prototypes(header):
+    out = {}
+    src = _strip_c(open(os.path.join(ROOT, "include", header)).read())
+    for ret, name, args in re.findall(r"^\s*((?:const\s+)?\w+\s*\*?)\s*((?:rt)_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.M | re.S):
+        params = []
+        if args.strip() != "void":
+            for a in [x.strip() for x in args.split(",")]:
+                if a.startswith("RtProgressFn"):
+                    params.append(("fn", "RtProgressFn"))
+                    continue
+                m = re.match(r"(.*?[\s\*])(\w+)\s*(?:\[\d*\])?$", a, flags=re.S)
+                assert m, a
+                ty = _c_type_to_rust(m.group(1))
+                if "[" in a:  # a parameter array is a pointer to its element
+                    ty = "*mut " + ty
+                params.append((m.group(2), ty))
+        out[name] = (params, None if ret.strip() == "void" else _c_type_to_rust(ret))
+    return out
+
+
+def _norm_rust_type(t):
+    t = re.sub(r"std::(ffi|os::raw)::", "", t.strip())
+    return re.sub(r"\s+", " ", t)
+
+
+def _rust_blocks():
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = md[md.index("## 1."):md.index("## 2.")]
+    text = "\n".join(re.findall(r"```rust\n(.*?)```", sec, flags=re.S))
+    text = re.sub(r"//[^\n]*", "", text)
+    structs, protos = {}, {}
+    for name, body in re.findall(r"#\[repr\(C\)\]\s*pub struct (\w+)\s*\{(.*?)\}", text, flags=re.S):
+        fields = []
+        for f in [x.strip() for x in re.split(r",(?![^\[]*\])", body) if x.strip()]:
+            m = re.match(r"pub (\w+)\s*:\s*(.+)$", f, flags=re.S)
+            assert m, f
+            fields.append((m.group(1), _norm_rust_type(m.group(2))))
+        structs[name] = fields
+    for name, args, ret in re.findall(r"pub fn (rt_\w+)\s*\((.*?)\)\s*(?:->\s*([^;]+))?;", text, flags=re.S):
+        params = []
+        depth, cur = 0, ""
+        for ch in args:  # split on top-level commas (the callback type has its own parentheses)
+            depth += ch in "(<[" 
+            depth -= ch in ")>]"
+            if ch == "," and depth == 0:
+                params.append(cur), (cur := "")
+            else:
+                cur += ch
+        if cur.strip():
+            params.append(cur)
+        plist = []
+        for a in params:
+            pname, ty = a.split(":", 1)
+            ty = _norm_rust_type(ty)
+            plist.append((pname.strip(), "RtProgressFn" if ty.startswith("Option<extern") else ty))
+        protos[name] = (plist, _norm_rust_type(ret) if ret else None)
+    return structs, protos
+
+
+def test_rust_binding_text_matches_the_headers():
+    """INTEGRATION.md section 1 is the binding a maintainer of the reference pastes into src/gpu.rs; no rustc here checks it, so
+    this does: every #[repr(C)] struct has the header's fields in the header's order with the corresponding types, and every
+    `pub fn` the header's arguments (count, order, types) and return type.  Both headers, nothing missing on either side."""
+    r_structs, r_protos = _rust_blocks()
+    c_structs, c_protos = {}, {}
+    for h in (PRODUCT_HEADER, DEBUG_HEADER):
+        c_structs.update(_c_structs(h))
+        c_protos.update(_c_prototypes(h))
+    assert set(r_structs) == set(c_structs), set(r_structs) ^ set(c_structs)
+    for name, fields in c_structs.items():
+        assert r_structs[name] == fields, (name, [(a, b) for a, b in zip(r_structs[name], fields) if a != b])
+    assert set(r_protos) == set(c_protos), set(r_protos) ^ set(c_protos)
+    for name, (params, ret) in c_protos.items():
+        rp, rr = r_protos[name]
+        assert [t for _, t in rp] == [t for _, t in params], (name, rp, params)
+        assert rr == ret, (name, rr, ret)
+    # the first Rust block is the product header and nothing else
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    first = re.findall(r"```rust\n(.*?)```", md[md.index("## 1."):], flags=re.S)[0]
+    assert sorted(re.findall(r"pub fn (rt_\w+)", first)) == _declared_functions(PRODUCT_HEADER)
+
+
+def test_c_host_example_needs_only_the_product_headers(tmp_path):
+    """examples/host_main.c compiles against rtow_host.h + rtow_mi355x.h in a directory that does not hold the debug header."""
+    inc = tmp_path / "include"
+    inc.mkdir()
+    for h in ("rtow_host.h", PRODUCT_HEADER):
+        (inc / h).write_text(open(os.path.join(ROOT, "include", h)).read())
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", str(inc), "-c", os.path.join(ROOT, "examples", "host_main.c"),
+                    "-o", str(tmp_path / "host_main.o")], check=True)
 
 
 def test_shard_helpers_need_no_gpu(rt):

@@ -263,6 +263,41 @@ def test_bounce_every_texture_and_sky(rt, orc, renderer, tex):
     _check_bounce(rt, orc, renderer, scene, n=20000, seed=6)
 
 
+@pytest.mark.parametrize("where,radius", [(5e7, 1000.0), (1e10, 1e6), (-3e9, 4e5), (3e19, 4e15)])
+def test_perlin_lattice_index_far_from_the_origin(rt, orc, renderer, where, radius):
+    """`p.x.floor() as isize` then rem_euclid(256) (texture.rs:126-138) for coordinates beyond 2^31 — reached by the seventh octave
+    (p * 64) of a hit 3.4e7 units out, by every octave at 1e10, and beyond isize at 3e19 — where a 32-bit conversion saturates to an
+    odd index and the reference's 64-bit one lands on a multiple of 256.  One axis far, the other two small enough to have
+    fractional parts, so that the gradients of the far axis' lattice index do contribute; colours against the oracle."""
+    s = rt.Scene.new()
+    marble = s.material(rt._ffi.MAT_EMISSION, tex0=s.perlin_tex(4.0))  # emitted = the texture itself, no random number involved
+    s.sphere((where, 0.0, 0.0), radius, marble, "far marble")
+    s.sphere((0.0, where, 0.0), radius, marble, "far marble y")
+    s.sphere((0.0, 0.0, -where), radius, marble, "far marble z")
+    s.set_sky(rt._ffi.SKY_BLACK, None)
+    s.set_camera((0, 0, 0), (where, 0, 0), (0, 1, 0), 20, 1.0)
+    scene = s.finish()
+    renderer.upload(scene)
+    rng = np.random.default_rng(17)
+    n = 6000
+    centres = np.array([(where, 0, 0), (0, where, 0), (0, 0, -where)], np.float64)
+    target = centres[rng.integers(0, 3, n)] + rng.uniform(-0.7, 0.7, (n, 3)) * radius
+    o = (target * (1.0 - 4.0 * radius / abs(where)) + rng.uniform(-0.1, 0.1, (n, 3)) * radius).astype(np.float32)
+    d = (target - o.astype(np.float64))
+    d = (d / np.linalg.norm(d, axis=1)[:, None]).astype(np.float32)
+    ln = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]).astype(np.float32)
+    d = (d * (np.float32(1) / ln)[:, None]).astype(np.float32)
+    keys = rng.integers(0, 2**32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+    g = renderer.debug_bounce(o, d, keys, depth=1)
+    c = orc.debug_bounce(scene.flat_ptr, o, d, keys, depth=1, accel=orc.ACCEL_LIST)
+    assert np.array_equal(g["hit"], c["hit"]) and (g["hit"] >= 0).mean() > 0.5
+    assert np.array_equal(g["t"].view(np.uint32), c["t"].view(np.uint32))
+    a, b = g["radiance"].astype(np.float64), c["radiance"].astype(np.float64)
+    assert np.isfinite(b).all() and np.allclose(a, b, rtol=2e-5, atol=2e-5), np.abs(a - b).max()
+    assert len(np.unique(np.round(b[g["hit"] >= 0, 0], 3))) > 50  # a marble, not a constant: the lookups matter
+    _check_production_kernels(rt, orc, renderer, scene, o, d, 1)
+
+
 def test_bvh_equals_brute_force_on_adversarial_rays(rt, orc, renderer):
     """Axis-aligned directions (zero components -> infinite slab reciprocals), origins inside
     spheres, on sphere surfaces, far away, and grazing rays: BVH == list walk == oracle, bit for bit."""
@@ -1686,7 +1721,8 @@ def test_random_scenes_bounce_parity(rt, orc, renderer, seed):
     assert np.array_equal(g["t"][~med].view(np.uint32), c["t"][~med].view(np.uint32))
     assert np.allclose(g["t"][med], c["t"][med], rtol=4e-6)
     assert np.array_equal(g["d"].view(np.uint32), c["d"].view(np.uint32))
-    assert np.allclose(g["o"], c["o"], rtol=1e-5, atol=1e-4)
+    assert np.array_equal(g["o"][~med].view(np.uint32), c["o"][~med].view(np.uint32))  # origins exact, like t, except a medium's scatter point (ln)
+    assert np.allclose(g["o"][med], c["o"][med], rtol=1e-5, atol=1e-4)
     for k in ("radiance", "attenuation"):
         a_, c_ = g[k].astype(np.float64), c[k].astype(np.float64)
         fin = np.isfinite(c_)
