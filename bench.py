@@ -14,7 +14,8 @@ HBM.  With N > 1 ranks (one process per GPU, torch.distributed, backend nccl == 
 sharded in interleaved bands of 8 rows and each step ends with the gather of the band buffers to rank 0.
     --scaling weak    (default for config 2) per-GPU work fixed: every rank renders (ny/N rows) x nx x spp*N samples
     --scaling strong  (default for configs 3-5) the stated frame split over the N ranks
-With N > 1 and no --config the line is config 3 strong, and a short config-2 weak leg (2 steps) rides along under "also";
+With N > 1 and no --config the line is config 3 strong, and a short config-2 weak leg (2 steps) rides along under "also"; each names
+the committed one-GPU line of its frame on the same kernels ("single_gpu_reference": efficiency = value / (N x its value));
 the line carries the gather time per step ("gather_ms", HIP events around the gather + rank 0's de-interleave) and the trace-step
 HBM fraction of every rank ("roofline.per_rank").
 
@@ -97,6 +98,31 @@ def pmc_valu(workload_key, build_id):
                    "v_add_f32 rate of scripts/micro/mul_rate.hip at 8 waves per SIMD (2.1 cycles per wave64 instruction on the "
                    "SIMD-32, profiles/round2/valu_peak.json), so issue_frac <= 1; lane_util = active lanes per issued instruction")
     return out
+
+
+def single_gpu_reference(config_id, metric, build_id, profiles_root=None):
+    """The like-for-like one-GPU figure for a run on N > 1 GPUs: the committed `bench.py --config <id>` line of ONE GPU for the
+    same frame (profiles/round*/bench_config<id>.json: same metric label = same nx, ny, spp) taken on THESE kernels — a record of
+    another build is refused, as the PMC files are.  With it scaling efficiency = value / (n_gpus x reference value) can be read
+    off the one line.  Returns the dict for the "single_gpu_reference" key (value None and a reason when there is no such record)."""
+    import glob
+    root = profiles_root or os.path.join(ROOT, "profiles")
+    reason = f"no profiles/round*/bench_config{config_id}.json"
+    best = None
+    for p in sorted(glob.glob(os.path.join(root, "round*", f"bench_config{config_id}.json"))):
+        try:
+            t = json.load(open(p))
+        except (OSError, ValueError):
+            continue
+        if t.get("n_gpus") != 1 or t.get("metric") != metric or not t.get("value"):
+            reason = f"{os.path.relpath(p, os.path.dirname(root))} is not a one-GPU line of this frame"
+            continue
+        if t.get("library_build_id") != build_id:
+            reason = f"{os.path.relpath(p, os.path.dirname(root))} was taken on build {t.get('library_build_id')}, this library is {build_id}"
+            continue
+        best = {"config": config_id, "value": t["value"], "unit": t.get("unit", "Mray/s"), "ms_per_step": t.get("ms_per_step"),
+                "source": os.path.relpath(p, os.path.dirname(root)), "library_build_id": t["library_build_id"]}
+    return best or {"config": config_id, "value": None, "reason": reason}
 
 
 def usable_cores():
@@ -214,7 +240,7 @@ def in_library_check(rt, scene, renderer, frame, n_dev, timeout_s=150.0):
     return res
 
 
-def first_frame_child(cfg, nx, ny, spp, max_depth):
+def first_frame_child(cfg, nx, ny, spp, max_depth, prepare=True):
     """What the reference's own timer covers (utils.rs:15-18 around main.rs:70-126: scene build + render, ONE frame per process),
     measured in a process of its own: HIP runtime start, rt_ctx_create, host-side scene build (image decode included),
     rt_scene_upload and the first rt_render with its buffer allocations, wall clock; a second frame for comparison; and what the
@@ -231,13 +257,15 @@ def first_frame_child(cfg, nx, ny, spp, max_depth):
     import ray_tracing_in_one_weekend_amd as rt
     t_rt = time.perf_counter()
     renderer = rt.Renderer(0)
+    params = rt.make_params(nx, ny, spp, max_depth=max_depth, seed=95)
+    if prepare:  # the frame is known before the world is built (main.rs:64-67): its work buffers are requested meanwhile
+        renderer.prepare(params)
     t_ctx = time.perf_counter()
     rt.register_default_images()
     scene = rt.Scene.build(cfg["scene"], nx / ny)
     t_scene = time.perf_counter()
     renderer.upload(scene)
     t_up = time.perf_counter()
-    params = rt.make_params(nx, ny, spp, max_depth=max_depth, seed=95)
     _, _, st1 = renderer.render(scene.camera, params, want_rgb8=True, pinned=True)
     t_f1 = time.perf_counter()
     parts1 = renderer.render_parts()
@@ -247,7 +275,8 @@ def first_frame_child(cfg, nx, ny, spp, max_depth):
     parts2 = renderer.render_parts()
     ms = lambda a, b: round((b - a) * 1e3, 2)
     print(json.dumps({
-        "first_frame_ms": ms(t_rt, t_f1),  # rt_ctx_create + scene build + rt_scene_upload + first rt_render (f32 + RGB8 to the host)
+        "first_frame_ms": ms(t_rt, t_f1),  # rt_ctx_create (+ rt_prepare) + scene build + rt_scene_upload + first rt_render (f32 + RGB8 to the host)
+        "rt_prepare": bool(prepare),
         "parts_ms": {"hip_runtime_and_import": ms(t0, t_rt), "rt_ctx_create": ms(t_rt, t_ctx), "scene_build_host": ms(t_ctx, t_scene),
                      "rt_scene_upload": ms(t_scene, t_up), "first_rt_render": ms(t_up, t_f1), "second_rt_render": ms(t_f1, t_f2)},
         # rt_debug_render_parts: where the host spent the first rt_render (allocations one by one, the first kernel launch = code
@@ -333,7 +362,7 @@ def trace_roofline(trace_bytes, trace_s):
 
 
 def build_record(*, config_id, cfg, nx, ny, spp, spp_total, scaling, max_depth, band, world, backend, steps, warmup, elapsed_max,
-                 rays_total, gather_ms, per_rank, rank0, build_id, rendered=True):
+                 rays_total, gather_ms, per_rank, rank0, build_id, rendered=True, profiles_root=None):
     """The JSON line of rank 0 from the aggregated measurements (pure: the CPU test of the multi-rank launch path builds the
     same line from a rehearsal's numbers).  per_rank: [(trace_seconds, trace_bytes_algorithmic)] of every rank over the timed
     steps; rank0: dict of rank 0's last RtStats fields + launch totals (None when nothing was rendered)."""
@@ -388,6 +417,9 @@ def build_record(*, config_id, cfg, nx, ny, spp, spp_total, scaling, max_depth, 
                              "hit record between the kernels, i.e. the same 48 B per ray read and 40 B per survivor written"},
         "library_build_id": build_id,
     }
+    if world > 1:
+        # the same frame on ONE GPU with these kernels (committed record): efficiency = value / (n_gpus x this value)
+        out["single_gpu_reference"] = single_gpu_reference(config_id, out["metric"], build_id, profiles_root)
     if rendered:
         out["whole_path"] = {"bytes_algorithmic_per_step": int(r0["bytes_algorithmic"]),
                              "device_seconds_per_step": round(r0["seconds_device"], 6),
@@ -419,6 +451,7 @@ def main():
                     help="after the timed region, rank 0 also renders through rt_multi_render (one process, all --gpus devices, the RCCL "
                          "gather inside the library) and reports bit-identity with rt_render; always on when --gpus > 1")
     ap.add_argument("--first-frame-child", action="store_true", help=argparse.SUPPRESS)  # (the fresh process of first_frame())
+    ap.add_argument("--no-prepare", action="store_true", help=argparse.SUPPRESS)  # (first-frame child without the rt_prepare hint)
     ap.add_argument("--launcher-check", action="store_true",
                     help="rendezvous, world-size assertion and one framebuffer gather of a synthetic band buffer; no rendering "
                          "(the CPU test of the multi-rank launch path: RTOW_DIST_BACKEND=gloo, no GPU needed)")
@@ -426,7 +459,7 @@ def main():
 
     if args.first_frame_child:
         cfg = CONFIGS[args.config or 2]
-        first_frame_child(cfg, args.nx or cfg["nx"], args.ny or cfg["ny"], args.spp or cfg["spp"], args.max_depth)
+        first_frame_child(cfg, args.nx or cfg["nx"], args.ny or cfg["ny"], args.spp or cfg["spp"], args.max_depth, prepare=not args.no_prepare)
         return
     n_req = max(args.gpus, 1)
     if n_req > 1 and "WORLD_SIZE" not in os.environ:
@@ -639,6 +672,8 @@ def main():
             out["also"] = {k: r2[k] for k in ("metric", "value", "unit", "ms_per_step", "gather_ms", "scaling", "steps", "warmup")}
             out["also"]["workload"] = r2["config"]["workload"]
             out["also"]["roofline"] = {k: r2["roofline"][k] for k in ("achieved", "frac", "per_rank")}
+            # weak scaling: every rank does the work of the one-GPU headline frame, whose committed line is the reference
+            out["also"]["single_gpu_reference"] = single_gpu_reference(2, f"Mray/s (primary+secondary) at {c2['nx']}x{c2['ny']}/{c2['spp']}spp", build_id)
         if world == 1 and not args.timed_only:
             # the same frame handed to the HOST as the reference's output is (f32 frame + flipped RGB8 through rt_render into
             # page-locked memory of rt_host_alloc: the D2H copies included), never `value`: reported beside it

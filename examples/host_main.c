@@ -86,16 +86,26 @@ int main(int argc, char** argv) {
     if (image_dir && (register_ppm(image_dir, "earthmap.ppm", "res/earthmap.jpg") || register_ppm(image_dir, "newport_loft.ppm", "res/newport_loft.jpg")))
         return 1;
 
-    /* main.rs:74 — the scene function builds world + camera (and sets the sky, demo_scene.rs:38) */
-    if (rth_scene_build(scene_name, (float)nx / (float)ny, &scene) != 0) return fail("rth_scene_build", rth_last_error());
-    if (rth_scene_camera(scene, &cam) != 0) {
-        fail("rth_scene_camera", rth_last_error());
+    /* main.rs:72-73 — the workers: here one GPU.  The frame is known before the world is built (main.rs:64-67), so the context
+     * is told now and requests its work buffers on a thread of its own while this one builds the scene. */
+    if (rt_ctx_create(0, &ctx) != 0) {
+        fail("rt_ctx_create", rt_last_error(NULL));
+        goto done;
+    }
+    memset(&prm, 0, sizeof prm);
+    prm.nx = nx, prm.ny = ny, prm.spp = spp, prm.max_depth = max_depth, prm.seed = 95u;
+    if (rt_prepare(ctx, &prm) != 0) {
+        fail("rt_prepare", rt_last_error(ctx));
         goto done;
     }
 
-    /* main.rs:72-73 — the workers: here one GPU */
-    if (rt_ctx_create(0, &ctx) != 0) {
-        fail("rt_ctx_create", rt_last_error(NULL));
+    /* main.rs:74 — the scene function builds world + camera (and sets the sky, demo_scene.rs:38) */
+    if (rth_scene_build(scene_name, (float)nx / (float)ny, &scene) != 0) {
+        fail("rth_scene_build", rth_last_error());
+        goto done;
+    }
+    if (rth_scene_camera(scene, &cam) != 0) {
+        fail("rth_scene_camera", rth_last_error());
         goto done;
     }
     if (rt_scene_upload(ctx, rth_scene_flat(scene)) != 0) {
@@ -113,8 +123,6 @@ int main(int argc, char** argv) {
     }
 
     /* main.rs:77-108 — every pixel x every sample; main.rs:82 seeds column i with 95 + i, here 95 keys the counter RNG */
-    memset(&prm, 0, sizeof prm);
-    prm.nx = nx, prm.ny = ny, prm.spp = spp, prm.max_depth = max_depth, prm.seed = 95u;
     if (rt_render(ctx, &cam, &prm, frame, rgb8, &st) != 0) {
         fail("rt_render", rt_last_error(ctx));
         goto done;

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 9u /* 9: RT_OPT_MEDIUM_SEARCH, rt_debug_arithmetic (additions; every v8 layout and prototype unchanged) */
+#define RT_ABI_VERSION 10u /* 10: rt_prepare; the test hooks moved to rtow_mi355x_debug.h (every v9 layout and prototype unchanged) */
 
 /* error codes */
 #define RT_OK 0
@@ -277,6 +277,15 @@ uint32_t rt_shard_row_to_image_row(uint32_t local_row, uint32_t shard_band, uint
 int rt_render(RtCtx* ctx, const RtCamera* cam, const RtParams* params, float* out_rgb_f32,
               uint8_t* out_rgb8, RtStats* stats);
 
+/*
+ * Optional: tells the context which frame it will be asked for — nx, ny, spp, spp_slice and the shard fields of `params` are
+ * read, no scene is needed — so that the device memory for its work buffers (100 B per ray of a slice: 53 GB for 1920 x 1080 x
+ * 256 spp in one slice) is requested NOW, by a helper thread, while the host builds its scene.  The reference knows its frame
+ * before it builds the world (main.rs:64-67 against main.rs:74), and renders one frame per process: without the hint the first
+ * rt_render starts the same request itself and renders its first slices in what has arrived so far.  Returns at once.
+ */
+int rt_prepare(RtCtx* ctx, const RtParams* params);
+
 /* Pinned (page-locked) host memory for the two output images.  rt_render() writes a destination allocated here — or any
  * memory the caller has registered with the HIP runtime — by asynchronous copies at PCIe rate behind the last kernel; a
  * pageable destination (a plain Vec / malloc) works too and costs a staged copy (~3 ms instead of ~0.6 ms for a
@@ -315,15 +324,15 @@ int rt_set_progress(RtCtx* ctx, RtProgressFn fn, void* user);
  * SURVEY.md 8(b)/(e).  The reference's only parallelism is the per-column fan-out over a thread pool with the
  * world shared read-only (main.rs:72-108); here the scene is replicated on every device, device r renders the image
  * rows of the row-interleaved bands (j / band) % n == r (RNG keyed by pixel and sample: the frame does not depend on
- * n), ONE ncclAllGather over RCCL/xGMI brings the equal-sized band buffers together and the first device restores
- * row order.  librccl is opened at rt_multi_create (dlopen); the single-GPU entry points do not depend on it. */
+ * n), ONE gather over RCCL/xGMI — a group of ncclSend / ncclRecv to the first device — brings the equal-sized band buffers
+ * together and the first device restores row order.  librccl is opened at rt_multi_create (dlopen); the single-GPU entry points do not depend on it. */
 typedef struct RtMulti RtMulti;
 /* One RtCtx per listed HIP device + ncclCommInitAll over them.  Replaces main.rs:72-73 for a node.
  * N > 1 over RCCL is UNVERIFIED ON HARDWARE until an 8-GPU run of `bench.py --in-library` has been recorded (no box with
  * more than one GPU has been available to the build); everything around the collective — one host thread per context,
  * padded band buffers, the de-interleave, the statistics — runs for n = 2, 3 on one GPU through rt_multi_create_ex. */
 int rt_multi_create(const int* device_ids, int n_devices, RtMulti** out);
-/* Same with flags.  RT_MULTI_COPY_GATHER: the all_gather is replaced by device-to-device copies into the same gathered
+/* Same with flags.  RT_MULTI_COPY_GATHER: the RCCL gather is replaced by device-to-device copies into the same gathered
  * layout and librccl is not opened at all; a device id may then be listed several times (several contexts rendering
  * side by side on one GPU).  The test hook that reaches rt_multi_render's n > 1 code on a one-GPU box; frames are
  * bit-identical to rt_render either way. */
@@ -341,7 +350,7 @@ int rt_multi_scene_upload(RtMulti* m, const RtFlatScene* scene);
 int rt_multi_render(RtMulti* m, const RtCamera* cam, const RtParams* params, float* out_rgb_f32, uint8_t* out_rgb8,
                     RtStats* stats);
 /* The de-interleave step on its own: `d_gathered` is a DEVICE buffer of n_shards band buffers, each
- * max_r rt_shard_rows(ny, band, n_shards, r) rows of nx*3 floats (what the all_gather delivers); writes the frame in
+ * max_r rt_shard_rows(ny, band, n_shards, r) rows of nx*3 floats (what the gather delivers); writes the frame in
  * image row order to d_out_rgb_f32 [ny*nx*3] and / or the quantised, flipped image to d_out_rgb8 (device pointers,
  * either may be NULL).  `stream` as in rt_render_device. */
 int rt_deinterleave_bands(RtCtx* ctx, const void* d_gathered, uint32_t nx, uint32_t ny, uint32_t band, uint32_t n_shards,

@@ -63,7 +63,10 @@ enum RtDebugOption {
     RT_OPT_MATERIALISE_PRIMARIES = 11,/* 1: primary rays are written to the queue by their own kernel instead of regenerated */
     RT_OPT_MEDIUM_SEARCH = 12,        /* (upload) 1: ConstantMedium::hit evaluates its boundary twice, as the reference does, also where one
                                        * evaluation answers both searches (a box, a sphere) */
-    RT_OPT__COUNT = 13
+    RT_OPT_POOL_CHUNK_DELAY_US = 13,  /* n: the helper thread that backs the work-buffer pool (csrc/rt_pool.h) takes n microseconds longer per
+                                       * 128 MB chunk — a device that hands out memory slowly, for the test of frames that start in what
+                                       * has arrived so far */
+    RT_OPT__COUNT = 14
 };
 int rt_debug_set_option(RtCtx* ctx, uint32_t option, uint32_t value);
 int rt_debug_get_option(const RtCtx* ctx, uint32_t option, uint32_t* value);

@@ -99,12 +99,12 @@ RtProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C
 MULTI_COPY_GATHER = 1  # RT_MULTI_COPY_GATHER (rt_multi_create_ex)
 # enum RtDebugOption (rt_debug_set_option): per context, every setting renders the same bits
 (OPT_TREE_PLACEMENT, OPT_PRIMARY_LISTS, OPT_PIXEL_ORDER, OPT_TEXEL_POOL, OPT_GRID, OPT_GRID_CELL, OPT_CHAINS,
- OPT_GENERAL_KERNELS, OPT_GENERAL_LDS, OPT_QUEUE_SHARDS, OPT_ISECT_WORKGROUPS, OPT_MATERIALISE_PRIMARIES, OPT_MEDIUM_SEARCH) = range(13)
+ OPT_GENERAL_KERNELS, OPT_GENERAL_LDS, OPT_QUEUE_SHARDS, OPT_ISECT_WORKGROUPS, OPT_MATERIALISE_PRIMARIES, OPT_MEDIUM_SEARCH, OPT_POOL_CHUNK_DELAY_US) = range(14)
 OPT_NAMES = {"tree_placement": OPT_TREE_PLACEMENT, "primary_lists": OPT_PRIMARY_LISTS, "pixel_order": OPT_PIXEL_ORDER,
              "texel_pool": OPT_TEXEL_POOL, "grid": OPT_GRID, "grid_cell": OPT_GRID_CELL, "chains": OPT_CHAINS,
              "general_kernels": OPT_GENERAL_KERNELS, "general_lds": OPT_GENERAL_LDS, "queue_shards": OPT_QUEUE_SHARDS,
              "isect_workgroups": OPT_ISECT_WORKGROUPS, "materialise_primaries": OPT_MATERIALISE_PRIMARIES,
-             "medium_search": OPT_MEDIUM_SEARCH}
+             "medium_search": OPT_MEDIUM_SEARCH, "pool_chunk_delay_us": OPT_POOL_CHUNK_DELAY_US}
 
 
 class RtSceneInfo(C.Structure):
@@ -119,9 +119,9 @@ class RtSceneInfo(C.Structure):
         return d
 
 
-EXPECTED_ABI = 9  # RT_ABI_VERSION the struct layouts and prototypes below were written for
+EXPECTED_ABI = 10  # RT_ABI_VERSION the struct layouts and prototypes below were written for
 GPU_SYMBOLS = ["rt_abi_version", "rt_build_id", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
-               "rt_shard_rows", "rt_shard_row_to_image_row", "rt_render", "rt_render_device", "rt_debug_bounce", "rt_debug_arithmetic",
+               "rt_shard_rows", "rt_shard_row_to_image_row", "rt_prepare", "rt_render", "rt_render_device", "rt_debug_bounce", "rt_debug_arithmetic",
                "rt_get_depth_timings", "rt_set_progress", "rt_host_alloc", "rt_host_free", "rt_debug_set_option", "rt_debug_get_option",
                "rt_debug_scene_info", "rt_debug_grid_build", "rt_debug_render_parts", "rt_multi_create", "rt_multi_create_ex", "rt_multi_destroy", "rt_multi_device_count",
                "rt_multi_last_error", "rt_multi_scene_upload", "rt_multi_render", "rt_deinterleave_bands"]
@@ -166,6 +166,8 @@ def load_gpu_library():
     lib.rt_shard_rows.restype = C.c_uint32
     lib.rt_shard_row_to_image_row.argtypes = [C.c_uint32] * 4
     lib.rt_shard_row_to_image_row.restype = C.c_uint32
+    lib.rt_prepare.argtypes = [vp, C.POINTER(RtParams)]
+    lib.rt_prepare.restype = C.c_int
     lib.rt_render.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), _f, _u8, C.POINTER(RtStats)]
     lib.rt_render.restype = C.c_int
     lib.rt_render_device.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtParams), vp, vp, C.POINTER(RtStats)]

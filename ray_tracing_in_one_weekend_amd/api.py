@@ -234,6 +234,13 @@ class Renderer:
         if rc != 0:
             self._raise("rt_scene_upload", rc)
 
+    def prepare(self, params):
+        """rt_prepare: start requesting the work buffers of the frame `params` describes (a helper thread inside the library);
+        call it before building the scene, as a host that knows its frame size up front would (main.rs:64-67)."""
+        rc = self._lib.rt_prepare(self._ctx, C.byref(params))
+        if rc != 0:
+            self._raise("rt_prepare", rc)
+
     def set_option(self, option, value):
         """rt_debug_set_option: `option` an _ffi.OPT_* number or its lower-case name.  Per context; every setting renders the
         same bits (they select between equivalent search structures / placements / orders).  Upload-time options

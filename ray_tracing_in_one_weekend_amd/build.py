@@ -43,7 +43,7 @@ def build_gpu_debug_library(out=None):
 
 def gpu_sources():
     csrc = os.path.join(PKG_DIR, "csrc")
-    return [os.path.join(csrc, f) for f in ("rt_api.hip", "rt_kernels.h", "rt_device.h", "rt_bvh.h", "rt_grid.h", "rt_multi.h")] + \
+    return [os.path.join(csrc, f) for f in ("rt_api.hip", "rt_kernels.h", "rt_device.h", "rt_bvh.h", "rt_grid.h", "rt_multi.h", "rt_pool.h")] + \
            [os.path.join(ROOT, "include", "rtow_mi355x.h")]
 
 

@@ -5,6 +5,7 @@
 #include "rt_kernels.h"
 #include "rt_bvh.h"
 #include "rt_grid.h"
+#include "rt_pool.h"
 
 #include <hip/hip_runtime.h>
 
@@ -27,6 +28,7 @@ thread_local std::string g_create_error;
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool arena = false; // carved from the context's pool (rt_pool.h) instead of hipMalloc'ed: never freed on its own
 };
 
 } // namespace
@@ -43,10 +45,22 @@ struct RtCtx {
     // scene
     bool has_scene = false;
     DevScene ds{};
-    std::vector<void*> scene_allocs;
+    // Every device buffer of a context lies in its pool (rt_pool.h): the small persistent ones (scene, accumulator, counters,
+    // candidate lists, output images) are carved from the bottom by a bump pointer, the per-frame work buffers start above
+    // them.  Only the pool's helper thread ever asks the driver for device memory, so a request that the driver makes wait
+    // (seconds, now and then: scripts/micro/alloc_probe stallprobe) holds up the growth of the pool and nothing else —
+    // kernel launches, copies from pinned memory and events of the calling thread are not affected by it, its own
+    // hipMalloc would be (measured: 5.4 s).  A buffer that is outgrown is left behind (contexts hold a handful; the scene has a
+    // region of its own that re-uploads reuse); hipMalloc remains the fallback when the pool cannot serve.
+    size_t arena_top = 0;
+    DevBuf scene_region;       // the uploaded scene's arrays, bump-allocated (scene_used) and reused by the next upload
+    size_t scene_used = 0;
+    bool scene_measuring = false; // first pass of rt_scene_upload: upload() only adds up what it would need
+    size_t scene_measure = 0;
+    char* h_stage = nullptr;   // page-locked staging for host -> device copies (a pageable source costs ~30 ms on first use)
     // work buffers (grown on demand, reused across calls)
-    DevBuf qbuf[6];   // two queues x (a, b, c)
-    DevBuf rad, acc, counts, totals, out_f32, out_u8, dbg, qhit, genp, lists;
+    WorkPool pool;    // two ray queues, hit records, radiance slots: one virtual range grown by a helper thread (rt_pool.h)
+    DevBuf acc, counts, totals, out_f32, out_u8, dbg, genp, lists;
     std::vector<hipEvent_t> events;
     std::vector<hipEvent_t> depth_events;  // RT_FLAG_TIME_DEPTHS: 3 per depth (k_intersect begin, k_shade begin, k_shade end)
     int timed_depths = 0;
@@ -100,39 +114,74 @@ int fail(RtCtx* ctx, int code, const std::string& msg) {
         }                                                                                                  \
     } while (0)
 
-int ensure(RtCtx* ctx, DevBuf& b, size_t bytes) {
+constexpr size_t RT_STAGE_BYTES = 4u << 20;
+constexpr size_t RT_ARENA_MAX = 8ull << 30; // small buffers beyond this (frames of hundreds of megapixels) are hipMalloc'ed
+
+// `bytes` of the pool behind the buffers carved so far, or nullptr when the pool cannot give them (reservation spent, or the
+// device has no memory left for the chunks: the caller falls back to hipMalloc and its error text)
+void* arena_alloc(RtCtx* ctx, size_t bytes) {
+    const size_t off = (ctx->arena_top + 255u) & ~(size_t)255u;
+    const size_t need = off + bytes;
+    if (need > RT_ARENA_MAX) return nullptr;
+    if (pool_request(ctx->pool, need)) return nullptr;
+    if (!pool_wait(ctx->pool, need)) return nullptr;
+    ctx->arena_top = need;
+    return ctx->pool.base + off;
+}
+
+// plain = true: hipMalloc'ed whatever the pool could do (buffers that other devices or libraries address: rt_multi.h)
+int ensure(RtCtx* ctx, DevBuf& b, size_t bytes, bool plain = false) {
     if (bytes == 0) bytes = 16;
     if (b.bytes >= bytes) return RT_OK;
-    if (b.p) {
-        RT_HIP(ctx, hipFree(b.p));
-        b.p = nullptr;
-        b.bytes = 0;
-    }
+    if (b.p && !b.arena) RT_HIP(ctx, hipFree(b.p));
+    b = DevBuf{};
+    if (!plain)
+        if (void* p = arena_alloc(ctx, bytes)) {
+            b = DevBuf{p, bytes, true};
+            return RT_OK;
+        }
     RT_HIP(ctx, hipMalloc(&b.p, bytes));
     b.bytes = bytes;
     return RT_OK;
 }
 
 void free_buf(DevBuf& b) {
-    if (b.p) (void)hipFree(b.p);
-    b.p = nullptr;
-    b.bytes = 0;
+    if (b.p && !b.arena) (void)hipFree(b.p);
+    b = DevBuf{};
 }
 
-void free_scene(RtCtx* ctx) {
-    for (void* p : ctx->scene_allocs) (void)hipFree(p);
-    ctx->scene_allocs.clear();
+void free_scene(RtCtx* ctx) { // (the region stays: the next upload carves it again)
+    ctx->scene_used = 0;
     ctx->has_scene = false;
     std::memset(&ctx->ds, 0, sizeof(ctx->ds));
 }
 
+// host -> device through the page-locked staging buffer, on the context's stream, complete on return
+int copy_to_device(RtCtx* ctx, void* dst, const void* src, size_t bytes) {
+    for (size_t off = 0; off < bytes; off += RT_STAGE_BYTES) {
+        const size_t n = std::min(RT_STAGE_BYTES, bytes - off);
+        std::memcpy(ctx->h_stage, (const char*)src + off, n);
+        RT_HIP(ctx, hipMemcpyAsync((char*)dst + off, ctx->h_stage, n, hipMemcpyHostToDevice, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return RT_OK;
+}
+
 template <class T>
 int upload(RtCtx* ctx, const std::vector<T>& host, const T** dev) {
-    void* p = nullptr;
-    size_t bytes = std::max<size_t>(host.size() * sizeof(T), 16);
-    RT_HIP(ctx, hipMalloc(&p, bytes));
-    ctx->scene_allocs.push_back(p);
-    if (!host.empty()) RT_HIP(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    const size_t bytes = (std::max<size_t>(host.size() * sizeof(T), 16) + 255u) & ~(size_t)255u;
+    *dev = nullptr;
+    if (ctx->scene_measuring) {
+        ctx->scene_measure += bytes;
+        return RT_OK;
+    }
+    if (ctx->scene_used + bytes > ctx->scene_region.bytes) return fail(ctx, RT_ERR_NOMEM, "rt_scene_upload: scene region too small (internal)");
+    void* p = (char*)ctx->scene_region.p + ctx->scene_used;
+    ctx->scene_used += bytes;
+    if (!host.empty()) {
+        const int rc = copy_to_device(ctx, p, host.data(), host.size() * sizeof(T));
+        if (rc) return rc;
+    }
     *dev = reinterpret_cast<const T*>(p);
     return RT_OK;
 }
@@ -278,23 +327,40 @@ void launch_shade(RtCtx* ctx, hipStream_t sg, bool gen, bool fused_lists, uint32
 #undef RT_LAUNCH_SHADE
 }
 
-// The work buffers of one ray queue (k = 0, 1) and the view the kernels get: qbuf[3k] holds the a / b records
-// (interleaved when RT_QSTRIDE is 2; qbuf[3k + 1] is the separate b array of the RT_QSTRIDE 1 build), qbuf[3k + 2] the c array.
-int ensure_queues(RtCtx* ctx, size_t n_rays) {
-    const size_t qbytes = n_rays * sizeof(float4);
+// Where the work buffers of a slice lie in the pool: two ray queues of n_queue rays (a / b records interleaved when RT_QSTRIDE is
+// 2, a separate b array in the RT_QSTRIDE 1 build; the c array), n_queue hit records, n_paths radiance slots.
+struct WorkLayout {
+    size_t q_ab[2], q_b[2], q_c[2], qhit, rad, total;
+};
+WorkLayout work_layout(size_t n_queue, size_t n_paths) {
+    WorkLayout w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255u) & ~(size_t)255u;
+        return o;
+    };
     for (int k = 0; k < 2; ++k) {
-        int rc;
-        if ((rc = ensure(ctx, ctx->qbuf[3 * k], RT_QSTRIDE * qbytes))) return rc;
-        if (RT_QSTRIDE == 1u && (rc = ensure(ctx, ctx->qbuf[3 * k + 1], qbytes))) return rc;
-        ctx->mark(k ? "alloc_queue1_ab" : "alloc_queue0_ab");
-        if ((rc = ensure(ctx, ctx->qbuf[3 * k + 2], qbytes / 2))) return rc;
-        ctx->mark(k ? "alloc_queue1_c" : "alloc_queue0_c");
+        w.q_ab[k] = take(RT_QSTRIDE * n_queue * sizeof(float4));
+        w.q_b[k] = RT_QSTRIDE == 1u ? take(n_queue * sizeof(float4)) : w.q_ab[k] + sizeof(float4);
+        w.q_c[k] = take(n_queue * sizeof(float2));
     }
-    return RT_OK;
+    w.qhit = take(n_queue * sizeof(float2));
+    w.rad = take(n_paths * RT_RAD_FLOATS * sizeof(float));
+    w.total = off;
+    return w;
 }
-Queue queue_view(RtCtx* ctx, int k) {
-    float4* a = (float4*)ctx->qbuf[3 * k].p;
-    return Queue{a, RT_QSTRIDE == 1u ? (float4*)ctx->qbuf[3 * k + 1].p : a + 1, (float2*)ctx->qbuf[3 * k + 2].p};
+struct WorkView {
+    Queue Q[2];
+    float2* qhit;
+    float* rad;
+};
+WorkView work_view(const RtCtx* ctx, const WorkLayout& w, size_t base) {
+    char* b = ctx->pool.base + base;
+    WorkView v;
+    for (int k = 0; k < 2; ++k) v.Q[k] = Queue{(float4*)(b + w.q_ab[k]), (float4*)(b + w.q_b[k]), (float2*)(b + w.q_c[k])};
+    v.qhit = (float2*)(b + w.qhit), v.rad = (float*)(b + w.rad);
+    return v;
 }
 
 // Queue geometry of a slice of n_max rays: shard count, k_intersect grid, shard capacity.
@@ -325,6 +391,51 @@ QueueGeom queue_geom(const RtCtx* ctx, uint32_t n_max) {
     const uint32_t nchunks = (n_max + 255u) / 256u;
     g.cap = ((nchunks + g.nq - 1) / g.nq) * 256u;
     return g;
+}
+
+// ---- slice sizing (rt_prepare and render_impl) ----------------------------------------------------------------
+// A ray of a slice costs 100 B of work buffers (two 40 B queues, 8 B hit record, 12 B radiance slot).  Few, large slices amortise
+// the short-queue tail of the bounce loop (depths > ~12 hold a few thousand rays: config 2 measured 99 / 88 / 82 / 79.5 ms per
+// frame with 8 / 4 / 2 / 1 slices), so the library's own choice is up to 640 Mi rays (65 GiB of the 288 GB HBM) and never more
+// than half of what the device has free.
+uint32_t queue_shards(const RtCtx* ctx) { return ctx->opt[RT_OPT_QUEUE_SHARDS] ? ctx->opt[RT_OPT_QUEUE_SHARDS] : (uint32_t)ctx->n_cu * 8u; }
+size_t slice_bytes(const RtCtx* ctx, uint32_t npix, uint32_t sc) {
+    const uint32_t nq = queue_shards(ctx), n_max = npix * sc;
+    const uint32_t cap = (((n_max + 255u) / 256u + nq - 1u) / nq) * 256u; // (queue_geom's shard capacity)
+    return work_layout((size_t)nq * cap, n_max).total;
+}
+// the most samples per pixel (<= sc_max) whose slice fits `bytes`; 0 when not even one does
+uint32_t slice_fit(const RtCtx* ctx, uint32_t npix, size_t bytes, uint32_t sc_max) {
+    uint32_t sc = (uint32_t)std::min<uint64_t>(sc_max, bytes / (100ull * npix) + 1u);
+    while (sc > 0u && slice_bytes(ctx, npix, sc) > bytes) --sc;
+    return sc;
+}
+struct SlicePlan {
+    uint32_t S_cap;    // most samples per pixel a slice may hold
+    bool by_library;   // RtParams.spp_slice == 0: the library chose, and may start a frame with smaller slices while the pool grows
+    size_t want_bytes; // pool size that holds such a slice
+};
+// (the work buffers of a slice start at work_base(ctx): behind the small persistent buffers carved from the pool so far)
+size_t work_base(const RtCtx* ctx) { return (ctx->arena_top + 4095u) & ~(size_t)4095u; }
+int plan_slices(RtCtx* ctx, const RtParams* prm, uint64_t npix64, SlicePlan& pl) {
+    const uint32_t spp = prm->spp;
+    uint32_t S = prm->spp_slice;
+    pl.by_library = S == 0u;
+    if (pl.by_library) S = (uint32_t)std::max<uint64_t>(1, (640ull << 20) / npix64);
+    S = std::min(std::min(S, spp), 1u << 20); // udiv_inv (slot -> sample, pixel) wants quotients below 2^21
+    if ((uint64_t)S * npix64 > 0xFFFFFF00ull) S = (uint32_t)(0xFFFFFF00ull / npix64);
+    if (S == 0) return fail(ctx, RT_ERR_UNSUPPORTED, "render: shard has more than 2^32 pixels");
+    const uint32_t npix = (uint32_t)npix64;
+    if (pl.by_library) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t half = (free_b + ctx->pool.mapped.load()) / 2u, base = work_base(ctx);
+            if (base + slice_bytes(ctx, npix, S) > half) S = std::max(1u, slice_fit(ctx, npix, half > base ? half - base : 0u, S));
+        }
+    }
+    pl.S_cap = S;
+    pl.want_bytes = work_base(ctx) + slice_bytes(ctx, npix, S);
+    return RT_OK;
 }
 
 } // namespace
@@ -362,8 +473,11 @@ int rt_ctx_create(int device_id, RtCtx** out_ctx) {
         return RT_ERR_NOMEM;
     }
     ctx->device = device_id;
+    ctx->pool.device = device_id;
     auto bail = [&](const char* what, hipError_t err) {
         g_create_error = std::string("rt_ctx_create: ") + what + ": " + hipGetErrorString(err);
+        if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
+        pool_destroy(ctx->pool);
         delete ctx;
         return RT_ERR_DEVICE;
     };
@@ -401,6 +515,10 @@ int rt_ctx_create(int device_id, RtCtx** out_ctx) {
     if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipHostMalloc((void**)&ctx->h_overflow, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void**)&ctx->h_stage, RT_STAGE_BYTES, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    // the pool's helper thread starts backing the bottom of the range now (the scene and the small buffers will lie there): the
+    // first mapping of a process costs 10-30 ms, which overlap the host's scene construction this way
+    (void)pool_request(ctx->pool, 256u << 20);
     *out_ctx = ctx;
     return RT_OK;
 }
@@ -411,9 +529,9 @@ void rt_ctx_destroy(RtCtx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     free_scene(ctx);
-    for (auto& b : ctx->qbuf) free_buf(b);
-    free_buf(ctx->rad), free_buf(ctx->acc), free_buf(ctx->counts), free_buf(ctx->totals);
-    free_buf(ctx->out_f32), free_buf(ctx->out_u8), free_buf(ctx->dbg), free_buf(ctx->qhit), free_buf(ctx->genp);
+    free_buf(ctx->scene_region);
+    free_buf(ctx->acc), free_buf(ctx->counts), free_buf(ctx->totals);
+    free_buf(ctx->out_f32), free_buf(ctx->out_u8), free_buf(ctx->dbg), free_buf(ctx->genp);
     free_buf(ctx->preview_u8), free_buf(ctx->lists);
     for (auto ev : ctx->events) (void)hipEventDestroy(ev);
     for (auto ev : ctx->depth_events) (void)hipEventDestroy(ev);
@@ -425,6 +543,8 @@ void rt_ctx_destroy(RtCtx* ctx) {
     for (auto sp : ctx->parked_streams) (void)hipStreamDestroy(sp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->h_overflow) (void)hipHostFree(ctx->h_overflow);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    pool_destroy(ctx->pool); // (after every buffer that may lie in it)
     delete ctx;
 }
 
@@ -800,7 +920,8 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     HostBvh4 bvh4;
     collapse_bvh4(bvh, bvh4);
 
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // the arrays of the scene before lie in the region the new ones are about to be written to: nothing may still read them
+    RT_HIP(ctx, hipDeviceSynchronize());
     free_scene(ctx);
     DevScene ds{};
     ds.n_xforms = s->n_xforms;
@@ -826,16 +947,32 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     int rc;
     std::vector<float4> pgeo(geo);
     pgeo.insert(pgeo.end(), rgeo.begin(), rgeo.end());
-    if ((rc = upload(ctx, pgeo, &ds.prim_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
-        (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
-        (rc = upload(ctx, pperm2, &ds.perlin_perm2)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
-        (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, texels8, &ds.texels8)) || (rc = upload(ctx, pmed, &ds.prim_medium)) || (rc = upload(ctx, med_prims, &ds.med_prims)) || (rc = upload(ctx, med_range, &ds.med_range)) || (rc = upload(ctx, med_xf, &ds.med_xform)) ||
-        (rc = upload(ctx, ent_bs, &ds.ent_bs)) || (rc = upload(ctx, entry_ids, &ds.ent_leaf)) ||
-        (rc = upload(ctx, med_nid, &ds.med_neg_inv_density)) || (rc = upload(ctx, pxf, &ds.prim_xform)) || (rc = upload(ctx, xparam, &ds.xf_param)) ||
-        (rc = upload(ctx, xmeta, &ds.xf_meta)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
-        (rc = upload(ctx, bvh4.p[0], &ds.bvh4_p[0])) || (rc = upload(ctx, bvh4.p[1], &ds.bvh4_p[1])) ||
-        (rc = upload(ctx, bvh4.p[2], &ds.bvh4_p[2])) || (rc = upload(ctx, bvh4.p[3], &ds.bvh4_p[3])) ||
-        (rc = upload(ctx, bvh4.p[4], &ds.bvh4_p[4])) || (rc = upload(ctx, bvh4.p[5], &ds.bvh4_p[5]))) {
+    auto upload_all = [&]() -> int {
+        int rc;
+        if ((rc = upload(ctx, pgeo, &ds.prim_geo)) || (rc = upload(ctx, smat, &ds.sph_mat)) || (rc = upload(ctx, mats, &ds.mats)) ||
+            (rc = upload(ctx, texs, &ds.texs)) || (rc = upload(ctx, pvec, &ds.perlin_vec)) ||
+            (rc = upload(ctx, pperm2, &ds.perlin_perm2)) || (rc = upload(ctx, imgs, &ds.imgs)) ||
+            (rc = upload(ctx, texels, &ds.texels)) || (rc = upload(ctx, texels8, &ds.texels8)) || (rc = upload(ctx, pmed, &ds.prim_medium)) || (rc = upload(ctx, med_prims, &ds.med_prims)) || (rc = upload(ctx, med_range, &ds.med_range)) || (rc = upload(ctx, med_xf, &ds.med_xform)) ||
+            (rc = upload(ctx, ent_bs, &ds.ent_bs)) || (rc = upload(ctx, entry_ids, &ds.ent_leaf)) ||
+            (rc = upload(ctx, med_nid, &ds.med_neg_inv_density)) || (rc = upload(ctx, pxf, &ds.prim_xform)) || (rc = upload(ctx, xparam, &ds.xf_param)) ||
+            (rc = upload(ctx, xmeta, &ds.xf_meta)) || (rc = upload(ctx, sclass, &ds.sph_class)) || (rc = upload(ctx, srec, &ds.sph_rec)) || (rc = upload(ctx, bvh4.id, &ds.bvh4_id)) ||
+            (rc = upload(ctx, bvh4.p[0], &ds.bvh4_p[0])) || (rc = upload(ctx, bvh4.p[1], &ds.bvh4_p[1])) ||
+            (rc = upload(ctx, bvh4.p[2], &ds.bvh4_p[2])) || (rc = upload(ctx, bvh4.p[3], &ds.bvh4_p[3])) ||
+            (rc = upload(ctx, bvh4.p[4], &ds.bvh4_p[4])) || (rc = upload(ctx, bvh4.p[5], &ds.bvh4_p[5]))) return rc;
+        return RT_OK;
+    };
+    // first pass: what the arrays need (upload() only adds up); then ONE region for them, the one of the scene before when it
+    // is large enough, else a new one from the pool (+ 25 %, + room for the grid's cell arrays) — no hipMalloc per array, none at
+    // all in the common case, and the copies go through page-locked staging
+    ctx->scene_measuring = true, ctx->scene_measure = 0;
+    (void)upload_all();
+    ctx->scene_measuring = false;
+    {
+        const size_t need = ctx->scene_measure + (1u << 20);
+        if (need > ctx->scene_region.bytes && (rc = ensure(ctx, ctx->scene_region, need + need / 4u))) return rc;
+        ctx->scene_used = 0;
+    }
+    if ((rc = upload_all())) {
         free_scene(ctx);
         return rc;
     }
@@ -925,58 +1062,37 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         return RT_OK;
     }
     const uint32_t npix = (uint32_t)npix64;
-    // slice size: few, large slices amortise the short-queue tail of the bounce loop (depths > ~12 hold a few
-    // thousand rays) — config 2 measured 99 / 88 / 82 / 79.5 ms per frame with 8 / 4 / 2 / 1 slices.  A ray of
-    // the slice costs 100 B of work buffers (two 40 B queues, 8 B hit record, 12 B radiance slot): up to 640 Mi
-    // rays (65 GiB of the 288 GB HBM), less when the device has less memory to give.
-    uint32_t S = prm->spp_slice;
-    if (S == 0) {
-        uint64_t max_rays = 640ull << 20;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            size_t held = ctx->rad.bytes + ctx->qhit.bytes;
-            for (const DevBuf& b : ctx->qbuf) held += b.bytes;
-            max_rays = std::min<uint64_t>(max_rays, (uint64_t)((double)(free_b + held) * 0.5 / (88.0 + 4.0 * RT_RAD_FLOATS)));
-        }
-        S = (uint32_t)std::max<uint64_t>(1, max_rays / npix64);
-    }
-    S = std::min(std::min(S, spp), 1u << 20); // udiv_inv (slot -> sample, pixel) wants quotients below 2^21
-    if ((uint64_t)S * npix64 > 0xFFFFFF00ull) S = (uint32_t)(0xFFFFFF00ull / npix64);
-    if (S == 0) return fail(ctx, RT_ERR_UNSUPPORTED, "render: shard has more than 2^32 pixels");
-    const uint32_t n_slices = (spp + S - 1) / S;
-    const uint32_t n_max = npix * S;
     const int n_depths = prm->max_depth + 1;
-
-    const QueueGeom qg = queue_geom(ctx, n_max);
-    const uint32_t nq = qg.nq, isect_grid = qg.isect_grid, cap = qg.cap;
+    const uint32_t nq = queue_shards(ctx);
     const bool use_bvh = ctx->use_bvh && !(prm->flags & RT_FLAG_BRUTE_FORCE);
     // depth 0 regenerates the primary ray in both kernels instead of materialising the queue
     const bool fuse_gen = use_bvh && ctx->opt[RT_OPT_MATERIALISE_PRIMARIES] != 1u;
+    // Candidate lists of the primary rays, once per frame (k_primary_lists): worth it when the samples of a pixel
+    // share them (>= 4 spp) and pixels see few entries.  Measured per 128-spp slice: sphere_scene (533 entries)
+    // 46.7 -> 41.9 ms, pbr_sweep_scene 41.2 -> 39.3, test_sphere 15.5 -> 14.8, cornell_box unchanged (its walls'
+    // bounding spheres cover every pixel: overflow); final_scene (3 408 entries, most pixels overflow) would pay
+    // 3 ms for nothing, hence the cap.
+    const bool want_lists = use_bvh && fuse_gen && spp >= 4 && ctx->ds.n_entries > 0 && ctx->ds.n_entries <= 2048 && ctx->opt[RT_OPT_PRIMARY_LISTS] != 1u;
 
-    if ((rc = ensure_queues(ctx, (size_t)nq * cap))) return rc;
-    if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
-    ctx->mark("alloc_hit_records");
-    if ((rc = ensure(ctx, ctx->rad, (size_t)n_max * RT_RAD_FLOATS * sizeof(float)))) return rc;
-    ctx->mark("alloc_radiance_slots");
+    // the small persistent buffers first (they lie at the bottom of the pool); the work buffers of the slices start above them
+    ctx->pool.chunk_delay_us.store(ctx->opt[RT_OPT_POOL_CHUNK_DELAY_US]);
     if ((rc = ensure(ctx, ctx->acc, (size_t)npix * 3 * sizeof(float)))) return rc;
     const size_t counts_bytes = (size_t)(n_depths + 1) * nq * sizeof(uint32_t); // queue sizes [depth][shard]
     if ((rc = ensure(ctx, ctx->counts, counts_bytes))) return rc;
     const size_t totals_bytes = (size_t)(n_depths + 2) * sizeof(unsigned long long);
     if ((rc = ensure(ctx, ctx->totals, totals_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->genp, sizeof(GenParams)))) return rc;
+    if (want_lists && (rc = ensure(ctx, ctx->lists, ((size_t)npix + 1u) * sizeof(uint4)))) return rc; // + the overflow counter behind the lists
     GenParams* gpd = (GenParams*)ctx->genp.p;
-    while (ctx->events.size() < 2 * (size_t)n_slices) {
-        hipEvent_t ev;
-        RT_HIP(ctx, hipEventCreate(&ev));
-        ctx->events.push_back(ev);
-    }
-    const Queue Q[2] = {queue_view(ctx, 0), queue_view(ctx, 1)};
-    float2* qhit = (float2*)ctx->qhit.p;
-    float* rad = (float*)ctx->rad.p;
     float* acc = (float*)ctx->acc.p;
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     unsigned long long* totals = (unsigned long long*)ctx->totals.p; // [0]=tex fetches [1]=bad dirs [2..]=rays per depth
-    ctx->mark("alloc_small_buffers_and_events");
+    SlicePlan plan;
+    if ((rc = plan_slices(ctx, prm, npix64, plan))) return rc;
+    if (const char* e = pool_request(ctx->pool, plan.want_bytes)) return fail(ctx, RT_ERR_NOMEM, std::string("render: ") + e);
+    const size_t wbase = work_base(ctx);
+    const uint32_t isect_grid = queue_geom(ctx, npix * plan.S_cap).isect_grid;
+    ctx->mark("small_buffers_and_pool_request");
 
     // (before the frame's own clock starts: once per launch stream, 0.3 ms of spin kernels; see ensure_concurrent_chains)
     if (nq >= 2u * RT_ISECT_MAX_SHARDS && (rc = ensure_concurrent_chains(ctx, st))) return rc;
@@ -994,7 +1110,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     }
     gp.nx = nx, gp.ny = ny, gp.npix = npix;
     gp.shard_band = band, gp.shard_count = scount, gp.shard_id = prm->shard_id;
-    gp.nq = nq, gp.cap = cap;
+    gp.nq = nq, gp.cap = 0u; // (cap: per slice)
     gp.seed_lo = (uint32_t)prm->seed, gp.seed_hi = (uint32_t)(prm->seed >> 32);
     gp.lists = nullptr;
     gp.n_overflow = nullptr;
@@ -1013,13 +1129,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         gp.tile_pixels = gp.tiles_per_row * 64u * (rows / 8u); // the last rows % 8 rows stay row-major
         gp.inv_tpr = gp.tiles_per_row ? inv(gp.tiles_per_row) : 0.0f;
     }
-    // Candidate lists of the primary rays, once per frame (k_primary_lists): worth it when the samples of a pixel
-    // share them (>= 4 spp) and pixels see few entries.  Measured per 128-spp slice: sphere_scene (533 entries)
-    // 46.7 -> 41.9 ms, pbr_sweep_scene 41.2 -> 39.3, test_sphere 15.5 -> 14.8, cornell_box unchanged (its walls'
-    // bounding spheres cover every pixel: overflow); final_scene (3 408 entries, most pixels overflow) would pay
-    // 3 ms for nothing, hence the cap.
-    if (use_bvh && fuse_gen && spp >= 4 && ctx->ds.n_entries > 0 && ctx->ds.n_entries <= 2048 && ctx->opt[RT_OPT_PRIMARY_LISTS] != 1u) {
-        if ((rc = ensure(ctx, ctx->lists, ((size_t)npix + 1u) * sizeof(uint4)))) return rc; // + the overflow counter behind the lists
+    if (want_lists) {
         gp.lists = (const uint4*)ctx->lists.p;
         uint32_t* n_overflow = (uint32_t*)((uint4*)ctx->lists.p + npix);
         gp.n_overflow = n_overflow;
@@ -1050,7 +1160,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             ctx->depth_events.push_back(ev);
         }
     }
-    IntersectParams ip{nq, cap, 0, 0u, nq};
+    IntersectParams ip{nq, 0u, 0, 0u, nq};
     // Two shard groups on two streams: k_intersect is bound by VALU issue and leaves HBM idle, k_shade past depth 0
     // waits on HBM and leaves the VALUs idle (profiles/round2).  Each half of the shards runs its own chain
     // intersect -> shade -> intersect ... on its own stream; the two chains drift apart because the kernels differ in
@@ -1070,9 +1180,50 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
     const uint32_t shards_per_wg = (nq + isect_grid - 1u) / isect_grid;
     // selects the "general scene" kernel instantiations (rectangles and Translate / RotateY wrappers)
     const bool rects = scene_is_general(ctx);
-    for (uint32_t sl = 0; sl < n_slices; ++sl) {
-        const uint32_t s0 = sl * S;
-        const uint32_t sc = std::min(S, spp - s0);
+    // Slices: as many samples per pixel as the plan allows and the pool holds NOW.  While the helper thread is still backing the
+    // pool (the first frame of a process, rt_pool.h) a frame whose slice size the library chose starts with what is mapped — at
+    // least 1/32 of its samples, one such slice ahead of the device at most — instead of waiting for the rest; slices are
+    // independent and the frame is bit-identical for any slicing.  A slice size the caller asked for is waited for.
+    uint32_t n_slices = 0, s0 = 0;
+    const uint32_t S_progress = std::min(plan.S_cap, std::max(1u, (spp + 31u) / 32u));
+    double pool_wait_ms = 0.0;
+    while (s0 < spp) {
+        const uint32_t sl = n_slices;
+        const uint32_t sc_max = std::min(plan.S_cap, spp - s0);
+        uint32_t sc = 0;
+        for (;;) {
+            const size_t mapped = ctx->pool.mapped.load();
+            const uint32_t fits = slice_fit(ctx, npix, mapped > wbase ? mapped - wbase : 0u, sc_max);
+            if (fits >= sc_max) { sc = sc_max; break; }
+            const bool growing = pool_growing(ctx->pool);
+            if (!growing) { // the device had no more to give: the frame takes more slices; nothing at all is an error
+                if (ctx->pool.mapped.load() != mapped) continue;
+                if (fits == 0u) return fail(ctx, RT_ERR_NOMEM, "render: no device memory for the work buffers of one sample per pixel (" +
+                                                                    std::to_string(slice_bytes(ctx, npix, 1u) >> 20) + " MB): " + pool_error(ctx->pool));
+                sc = fits;
+                break;
+            }
+            // one small slice ahead of the device at most: the next is cut when the device is about to run dry
+            const bool device_idle = sl == 0u || hipEventQuery(ctx->events[2 * (size_t)sl - 1]) == hipSuccess;
+            if (plan.by_library && fits >= std::min(S_progress, sc_max) && device_idle) { sc = fits; break; }
+            const auto tw = std::chrono::steady_clock::now();
+            pool_wait_progress(ctx->pool, mapped, 200u);
+            pool_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+        }
+        (void)hipGetLastError(); // (hipEventQuery: hipErrorNotReady is not an error)
+        const uint32_t n_max = npix * sc;
+        const uint32_t cap = queue_geom(ctx, n_max).cap;
+        const WorkView wv = work_view(ctx, work_layout((size_t)nq * cap, n_max), wbase);
+        const Queue* Q = wv.Q;
+        float2* qhit = wv.qhit;
+        float* rad = wv.rad;
+        gp.cap = cap, ip.cap = cap;
+        while (ctx->events.size() < 2 * (size_t)(sl + 1u)) {
+            hipEvent_t ev;
+            RT_HIP(ctx, hipEventCreate(&ev));
+            ctx->events.push_back(ev);
+        }
+        ++n_slices;
         gp.s0 = s0;
         gp.n_rays = npix * sc;
         RT_HIP(ctx, hipMemsetAsync(counts, 0, counts_bytes, st));
@@ -1128,7 +1279,7 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         RT_HIP(ctx, hipEventRecord(ctx->events[2 * sl + 1], st));
         hipLaunchKernelGGL(k_resolve, dim3((npix + 255u) / 256u), dim3(256), 0, st, rad, acc, npix, sc);
         hipLaunchKernelGGL(k_accum_counts, dim3((unsigned)n_depths), dim3(256), 0, st, counts, nq, (uint32_t)n_depths, totals + 2);
-        if (ctx->progress_armed && ctx->progress_fn && sl + 1 < n_slices) { // the last slice is the final image itself
+        if (ctx->progress_armed && ctx->progress_fn && s0 + sc < spp) { // the last slice is the final image itself
             const uint32_t done = s0 + sc;
             hipLaunchKernelGGL(k_finalize, dim3((npix + 255u) / 256u), dim3(256), 0, st, acc, (float*)nullptr,
                                (uint8_t*)ctx->preview_u8.p, nx, rows, done, gp.tiles_per_row, gp.tile_pixels);
@@ -1136,7 +1287,9 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
             RT_HIP(ctx, hipStreamSynchronize(st));
             ctx->progress_fn(ctx->progress_user, done, spp, ctx->preview_host.data(), nx, rows);
         }
+        s0 += sc;
     }
+    if (pool_wait_ms > 0.0) ctx->parts.emplace_back("of_which_waiting_for_the_pool", pool_wait_ms);
     hipLaunchKernelGGL(k_finalize, dim3((npix + 255u) / 256u), dim3(256), 0, st, acc, (float*)d_out_rgb_f32,
                        (uint8_t*)d_out_rgb8, nx, rows, spp, gp.tiles_per_row, gp.tile_pixels);
     RT_HIP(ctx, hipEventRecord(ctx->ev_end, st));
@@ -1179,6 +1332,25 @@ static int render_impl(RtCtx* ctx, const RtCamera* cam, const RtParams* prm, voi
         stats->n_slices = n_slices;
         stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
     }
+    return RT_OK;
+}
+
+int rt_prepare(RtCtx* ctx, const RtParams* prm) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!prm || prm->nx == 0 || prm->ny == 0 || prm->spp == 0) return fail(ctx, RT_ERR_INVALID, "rt_prepare: params NULL, or nx, ny or spp 0");
+    if (prm->shard_count > 1 && prm->shard_id >= prm->shard_count) return fail(ctx, RT_ERR_INVALID, "rt_prepare: shard_id >= shard_count");
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t npix64 = (uint64_t)rt_shard_rows(prm->ny, prm->shard_band ? prm->shard_band : 1u, prm->shard_count, prm->shard_id) * prm->nx;
+    if (npix64 == 0) return RT_OK;
+    if (npix64 > 0xFFFFFFFFull) return fail(ctx, RT_ERR_INVALID, "rt_prepare: image too large");
+    SlicePlan plan;
+    int rc = plan_slices(ctx, prm, npix64, plan);
+    if (rc) return rc;
+    ctx->pool.chunk_delay_us.store(ctx->opt[RT_OPT_POOL_CHUNK_DELAY_US]);
+    // + what the frame's small buffers will take below the work area (accumulator, candidate lists, the two output images: 43 B a
+    // pixel) and the scene (an estimate: a pool that turns out a little short simply keeps growing while the frame starts)
+    const size_t small = (size_t)npix64 * 48u + (64u << 20);
+    if (const char* e = pool_request(ctx->pool, plan.want_bytes + small)) return fail(ctx, RT_ERR_NOMEM, std::string("rt_prepare: ") + e);
     return RT_OK;
 }
 
@@ -1238,6 +1410,12 @@ int rt_debug_render_parts(const RtCtx* ctx, char* buf, uint32_t cap) {
         std::snprintf(num, sizeof(num), "\": %.3f", ctx->parts[k].second);
         js += (k ? ", \"" : "\"") + std::string(ctx->parts[k].first) + num;
     }
+    std::snprintf(num, sizeof(num), "%s\"pool_mapped_mb\": %zu", ctx->parts.empty() ? "" : ", ", ctx->pool.mapped.load() >> 20);
+    js += num;
+    std::snprintf(num, sizeof(num), ", \"pool_chunks_grown\": %u", ctx->pool.n_grown.load());
+    js += num;
+    std::snprintf(num, sizeof(num), ", \"pool_slowest_chunk_ms\": %.3f", ctx->pool.slowest_chunk_ms.load());
+    js += num;
     js += "}";
     if (buf && cap) {
         const size_t n = std::min<size_t>(js.size(), cap - 1u);
@@ -1332,14 +1510,16 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
     const QueueGeom qg = queue_geom(ctx, n);
     const uint32_t nq = qg.nq, cap = qg.cap;
     int rc;
-    if ((rc = ensure_queues(ctx, (size_t)nq * cap))) return rc;
-    if ((rc = ensure(ctx, ctx->qhit, (size_t)nq * cap * sizeof(float2)))) return rc;
-    if ((rc = ensure(ctx, ctx->rad, (size_t)n * RT_RAD_FLOATS * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->counts, (size_t)2 * nq * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->totals, 4 * sizeof(unsigned long long)))) return rc;
     if ((rc = ensure(ctx, ctx->genp, sizeof(GenParams)))) return rc;
     if ((rc = ensure(ctx, ctx->dbg, (size_t)n * 6 * sizeof(float)))) return rc;
-    const Queue Q[2] = {queue_view(ctx, 0), queue_view(ctx, 1)};
+    const WorkLayout wl = work_layout((size_t)nq * cap, n);
+    const size_t wbase = work_base(ctx);
+    if (const char* e = pool_request(ctx->pool, wbase + wl.total)) return fail(ctx, RT_ERR_NOMEM, std::string("rt_debug_bounce: ") + e);
+    if (!pool_wait(ctx->pool, wbase + wl.total)) return fail(ctx, RT_ERR_NOMEM, "rt_debug_bounce: no device memory for the work buffers: " + pool_error(ctx->pool));
+    const WorkView wv = work_view(ctx, wl, wbase);
+    const Queue* Q = wv.Q;
     uint32_t* counts = (uint32_t*)ctx->counts.p;
     float* d_o = (float*)ctx->dbg.p;
     float* d_d = d_o + 3 * (size_t)n;
@@ -1347,7 +1527,7 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
     RT_HIP(ctx, hipMemcpyAsync(d_d, io->in_d, 3 * (size_t)n * 4, hipMemcpyHostToDevice, st));
     RT_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)2 * nq * sizeof(uint32_t), st));
     RT_HIP(ctx, hipMemsetAsync(ctx->totals.p, 0, 4 * sizeof(unsigned long long), st));
-    RT_HIP(ctx, hipMemsetAsync(ctx->rad.p, 0xFF, (size_t)n * RT_RAD_FLOATS * sizeof(float), st)); // NaN pattern: a survivor has no slot
+    RT_HIP(ctx, hipMemsetAsync(wv.rad, 0xFF, (size_t)n * RT_RAD_FLOATS * sizeof(float), st)); // NaN pattern: a survivor has no slot
     // one "image row" of n pixels, one sample: slot i is pixel i, so its key is path_key(seed 0, pix i, sample 0)
     GenParams gp{};
     gp.nx = n, gp.ny = 1, gp.npix = n, gp.n_rays = n, gp.s0 = 0;
@@ -1358,7 +1538,7 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
     hipLaunchKernelGGL(k_init_counts, dim3((nq + 255u) / 256u), dim3(256), 0, st, gp, counts, (GenParams*)ctx->genp.p);
     hipLaunchKernelGGL(k_debug_fill, dim3((n + 255u) / 256u), dim3(256), 0, st, gp, Q[0], d_o, d_d);
     const bool use_bvh = ctx->use_bvh && !(io->flags & RT_FLAG_BRUTE_FORCE);
-    const StepBuffers sb{Q[0], Q[1], (float2*)ctx->qhit.p, counts, counts + nq, (float*)ctx->rad.p,
+    const StepBuffers sb{Q[0], Q[1], wv.qhit, counts, counts + nq, wv.rad,
                          (unsigned long long*)ctx->totals.p, (const GenParams*)ctx->genp.p};
     const IntersectParams ip{nq, cap, (int)io->depth, 0u, nq};
     launch_intersect(ctx, st, use_bvh, false, qg.isect_grid, sb, ip);
@@ -1369,7 +1549,7 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
     std::vector<float> hrad((size_t)n * RT_RAD_FLOATS);
     std::vector<float2> hc((size_t)nq * cap), hh((size_t)nq * cap);
     std::vector<uint32_t> hcnt((size_t)2 * nq);
-    RT_HIP(ctx, hipMemcpyAsync(hh.data(), ctx->qhit.p, hh.size() * sizeof(float2), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(hh.data(), wv.qhit, hh.size() * sizeof(float2), hipMemcpyDeviceToHost, st));
     std::vector<float4> hab; // RT_QSTRIDE 2: the interleaved a / b records, split on the host below
     if (RT_QSTRIDE == 1u) {
         RT_HIP(ctx, hipMemcpyAsync(ha.data(), Q[1].a, ha.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
@@ -1379,7 +1559,7 @@ static int debug_bounce_production(RtCtx* ctx, const RtBounceIO* io) {
         RT_HIP(ctx, hipMemcpyAsync(hab.data(), Q[1].a, hab.size() * sizeof(float4), hipMemcpyDeviceToHost, st));
     }
     RT_HIP(ctx, hipMemcpyAsync(hc.data(), Q[1].c, hc.size() * sizeof(float2), hipMemcpyDeviceToHost, st));
-    RT_HIP(ctx, hipMemcpyAsync(hrad.data(), ctx->rad.p, hrad.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipMemcpyAsync(hrad.data(), wv.rad, hrad.size() * sizeof(float), hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipMemcpyAsync(hcnt.data(), counts, hcnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipStreamSynchronize(st));
     for (size_t i = 0; i < hab.size() / 2; ++i) ha[i] = hab[2 * i], hb[i] = hab[2 * i + 1];

@@ -3,9 +3,10 @@
 // one process, n devices of one node, the framebuffer gather behind the C-ABI so that a Rust or C
 // host needs no torch and no RCCL code of its own.  Pixels are independent (RNG keyed by pixel and sample), so the
 // path shards with no exchange until the end: device r renders the image rows of the row-interleaved bands
-// (j / band) % n == r into an equal-sized band buffer, ONE ncclAllGather (RCCL; over xGMI every peer pair has its own
-// link, 12.4 MB per GPU at 4K) brings the buffers together and a kernel on the first device restores row order,
-// producing the f32 frame and the flipped RGB8 image of main.rs:98-105,127.
+// (j / band) % n == r into an equal-sized band buffer, ONE gather to the first device — a group of ncclSend / ncclRecv
+// (RCCL; over xGMI every peer pair has its own link, so the n - 1 transfers of 12.4 MB at 4K run side by side; only the
+// first device receives, as in the one-process-per-GPU path's dist.gather(dst=0)) — brings the buffers together and a
+// kernel on the first device restores row order, producing the f32 frame and the flipped RGB8 image of main.rs:98-105,127.
 //
 // librccl is opened with dlopen at rt_multi_create: the single-GPU entry points carry no RCCL dependency, and the
 // library still loads on a machine without RCCL.
@@ -53,16 +54,17 @@ struct RtMulti {
     void* lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::vector<ncclComm_t> comms;
-    bool copy_gather = false; // RT_MULTI_COPY_GATHER: device-to-device copies instead of ncclAllGather, no RCCL at all
-    std::vector<hipEvent_t> gather_done; // copy_gather: context i's copies have been enqueued up to this event
-    // per device: band buffer and gathered buffer; first device: full frame
-    std::vector<DevBuf> local, gathered;
-    DevBuf full_f32, full_u8;
+    bool copy_gather = false; // RT_MULTI_COPY_GATHER: device-to-device copies instead of ncclSend / ncclRecv, no RCCL at all
+    std::vector<hipEvent_t> gather_done; // copy_gather: context i's copy has been enqueued up to this event
+    // per device: band buffer; first device: the gathered band buffers and the full frame
+    std::vector<DevBuf> local;
+    DevBuf gathered, full_f32, full_u8;
 };
 
 namespace {
@@ -84,11 +86,10 @@ void rt_multi_destroy(RtMulti* m) {
     for (size_t i = 0; i < m->ctx.size(); ++i) {
         (void)hipSetDevice(m->devices[i]);
         if (i < m->local.size()) free_buf(m->local[i]);
-        if (i < m->gathered.size()) free_buf(m->gathered[i]);
     }
     if (!m->ctx.empty()) {
         (void)hipSetDevice(m->devices[0]);
-        free_buf(m->full_f32), free_buf(m->full_u8);
+        free_buf(m->gathered), free_buf(m->full_f32), free_buf(m->full_u8);
     }
     for (ncclComm_t c : m->comms)
         if (c && m->CommDestroy) (void)m->CommDestroy(c);
@@ -125,8 +126,8 @@ int rt_multi_create_ex(const int* device_ids, int n_devices, uint32_t flags, RtM
         m->ctx.push_back(c);
         m->devices.push_back(device_ids[i]);
     }
-    m->local.resize(n_devices), m->gathered.resize(n_devices);
-    if (copy_gather) { // no RCCL: the gather is n*n device-to-device copies ordered by one event per context
+    m->local.resize(n_devices);
+    if (copy_gather) { // no RCCL: the gather is n device-to-device copies ordered by one event per context
         m->copy_gather = true;
         m->gather_done.assign(n_devices, nullptr);
         for (int i = 0; i < n_devices; ++i) {
@@ -159,7 +160,8 @@ int rt_multi_create_ex(const int* device_ids, int n_devices, uint32_t flags, RtM
     if (!m->field) return bail(RT_ERR_UNSUPPORTED, std::string("rt_multi_create: librccl has no ") + sym)
     RT_RCCL_SYM(CommInitAll, "ncclCommInitAll");
     RT_RCCL_SYM(CommDestroy, "ncclCommDestroy");
-    RT_RCCL_SYM(AllGather, "ncclAllGather");
+    RT_RCCL_SYM(Send, "ncclSend");
+    RT_RCCL_SYM(Recv, "ncclRecv");
     RT_RCCL_SYM(GroupStart, "ncclGroupStart");
     RT_RCCL_SYM(GroupEnd, "ncclGroupEnd");
     RT_RCCL_SYM(GetErrorString, "ncclGetErrorString");
@@ -216,8 +218,9 @@ int rt_multi_render(RtMulti* m, const RtCamera* cam, const RtParams* params, flo
             rcs[i] = fail(c, RT_ERR_DEVICE, "hipSetDevice failed");
             return;
         }
-        if ((rcs[i] = ensure(c, m->local[i], band_floats * sizeof(float)))) return;
-        if ((rcs[i] = ensure(c, m->gathered[i], band_floats * sizeof(float) * n))) return;
+        // (plain hipMalloc: these are the buffers RCCL and the other devices' copy engines address)
+        if ((rcs[i] = ensure(c, m->local[i], band_floats * sizeof(float), true))) return;
+        if (i == 0 && (rcs[i] = ensure(c, m->gathered, band_floats * sizeof(float) * n, true))) return;
         if (hipMemsetAsync(m->local[i].p, 0, band_floats * sizeof(float), c->stream) != hipSuccess) { // the padding rows
             rcs[i] = fail(c, RT_ERR_DEVICE, "hipMemsetAsync failed");
             return;
@@ -235,31 +238,35 @@ int rt_multi_render(RtMulti* m, const RtCamera* cam, const RtParams* params, flo
     }
     for (uint32_t i = 0; i < n; ++i)
         if (rcs[i]) return multi_fail(m, rcs[i], std::string("device ") + std::to_string(m->devices[i]) + ": " + rt_last_error(m->ctx[i]));
-    // ---- the one exchange step: all_gather of the band buffers on the devices' own streams ------------------
+    // ---- the one exchange step: every band buffer to slot i of the first device's gathered buffer ---------------
+    float* const slots = (float*)m->gathered.p;
     if (m->copy_gather) {
-        // the same data movement as the all_gather — context i's band buffer into slot i of EVERY gathered buffer — as plain
-        // device-to-device copies on context i's stream; every stream then waits for all the others' copies
+        // the same data movement as plain device-to-device copies on context i's stream; the first context's stream then waits
+        // for all of them
         hipError_t e = hipSuccess;
         for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
             e = hipSetDevice(m->devices[i]);
-            for (uint32_t k = 0; k < n && e == hipSuccess; ++k)
-                e = hipMemcpyAsync((float*)m->gathered[k].p + (size_t)i * band_floats, m->local[i].p, band_floats * sizeof(float),
-                                   hipMemcpyDeviceToDevice, m->ctx[i]->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(slots + (size_t)i * band_floats, m->local[i].p, band_floats * sizeof(float), hipMemcpyDeviceToDevice, m->ctx[i]->stream);
             if (e == hipSuccess) e = hipEventRecord(m->gather_done[i], m->ctx[i]->stream);
         }
-        for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
-            e = hipSetDevice(m->devices[i]);
-            for (uint32_t k = 0; k < n && e == hipSuccess; ++k)
-                if (k != i) e = hipStreamWaitEvent(m->ctx[i]->stream, m->gather_done[k], 0);
-        }
+        if (e == hipSuccess) e = hipSetDevice(m->devices[0]);
+        for (uint32_t k = 1; k < n && e == hipSuccess; ++k) e = hipStreamWaitEvent(m->ctx[0]->stream, m->gather_done[k], 0);
         if (e != hipSuccess) return multi_fail(m, RT_ERR_DEVICE, std::string("rt_multi_render: copy gather: ") + hipGetErrorString(e));
     } else {
+        // device 0's own band is a local copy; devices 1 .. n-1 send, device 0 posts the matching receives — one group, so that
+        // RCCL sees every pair before it starts any ("grouped ncclSend / ncclRecv to rank 0")
+        if (hipSetDevice(m->devices[0]) != hipSuccess ||
+            hipMemcpyAsync(slots, m->local[0].p, band_floats * sizeof(float), hipMemcpyDeviceToDevice, m->ctx[0]->stream) != hipSuccess)
+            return multi_fail(m, RT_ERR_DEVICE, "rt_multi_render: copy of the first device's own band failed");
         ncclResult_t nr = m->GroupStart();
-        for (uint32_t i = 0; i < n && nr == ncclSuccess; ++i)
-            nr = m->AllGather(m->local[i].p, m->gathered[i].p, band_floats, ncclFloat, m->comms[i], m->ctx[i]->stream);
+        for (uint32_t i = 1; i < n && nr == ncclSuccess; ++i) {
+            nr = m->Send(m->local[i].p, band_floats, ncclFloat, 0, m->comms[i], m->ctx[i]->stream);
+            if (nr == ncclSuccess) nr = m->Recv(slots + (size_t)i * band_floats, band_floats, ncclFloat, (int)i, m->comms[0], m->ctx[0]->stream);
+        }
         const ncclResult_t ne = m->GroupEnd();
         if (nr == ncclSuccess) nr = ne;
-        if (nr != ncclSuccess) return multi_fail(m, RT_ERR_DEVICE, std::string("rt_multi_render: ncclAllGather: ") + m->GetErrorString(nr));
+        if (nr != ncclSuccess) return multi_fail(m, RT_ERR_DEVICE, std::string("rt_multi_render: ncclSend / ncclRecv: ") + m->GetErrorString(nr));
     }
     // ---- row order + quantisation on the first device, then to the host --------------------------------------
     RtCtx* c0 = m->ctx[0];
@@ -268,7 +275,7 @@ int rt_multi_render(RtMulti* m, const RtCamera* cam, const RtParams* params, flo
     int rc;
     if ((rc = ensure(c0, m->full_f32, n_px * 3u * sizeof(float))) || (out_rgb8 && (rc = ensure(c0, m->full_u8, n_px * 3u))))
         return multi_fail(m, rc, rt_last_error(c0));
-    if ((rc = rt_deinterleave_bands(c0, m->gathered[0].p, nx, ny, band, n, m->full_f32.p, out_rgb8 ? m->full_u8.p : nullptr, c0->stream)))
+    if ((rc = rt_deinterleave_bands(c0, m->gathered.p, nx, ny, band, n, m->full_f32.p, out_rgb8 ? m->full_u8.p : nullptr, c0->stream)))
         return multi_fail(m, rc, rt_last_error(c0));
     hipError_t e = hipSuccess;
     if (out_rgb_f32) e = hipMemcpyAsync(out_rgb_f32, m->full_f32.p, n_px * 3u * sizeof(float), hipMemcpyDeviceToHost, c0->stream);

@@ -9,22 +9,25 @@ log=$out/first_frame_states.txt
 P=scripts/micro/alloc_probe
 : > $log
 say() { echo "== $*" | tee -a $log; }
-child() { timeout -k 10 120 python bench.py --first-frame-child --config 2 2>&1 | grep '^{' >> $log; }
+child() { timeout -k 10 120 python bench.py --first-frame-child --config 2 $* 2>&1 | grep '^{' >> $log; }
 
 say "1. quiet device: allocation sizes"
 timeout -k 10 120 $P probe quiet >> $log 2>&1
-say "2. quiet device: first-frame child (twice)"
+say "2. quiet device: first-frame child (with rt_prepare twice, without once)"
 child
 child
+child --no-prepare
 say "3. right after a process that allocated, touched and freed 100 GB: small requests first, then sizes"
 timeout -k 10 120 $P churn 100 1 >> $log 2>&1
 timeout -k 10 120 $P small after_churn_100 6 64 >> $log 2>&1
 say "3b. churn again, then the size series"
 timeout -k 10 120 $P churn 100 1 >> $log 2>&1
 timeout -k 10 120 $P probe after_churn_100 >> $log 2>&1
-say "4. right after churn 100 GB: first-frame child"
+say "4. right after churn 100 GB: first-frame child, with and without rt_prepare"
 timeout -k 10 120 $P churn 100 1 >> $log 2>&1
 child
+timeout -k 10 120 $P churn 100 1 >> $log 2>&1
+child --no-prepare
 say "5. after 3 x 53 GB churn (three frames' worth of buffers freed): first-frame child"
 timeout -k 10 120 $P churn 53 3 >> $log 2>&1
 child

@@ -188,6 +188,139 @@ int main(int argc, char** argv) {
         }
         CK(hipMemAddressFree(base, total));
         std::printf("{\"mode\": \"vmm\", \"label\": \"%s\", \"unmap_release_all_ms\": %.1f}\n", label, ms_since(t0));
+    } else if (mode == "vmmmix") { // chunks of different sizes side by side, mapped by different threads: what does hipMemSetAccess accept?
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = 0;
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        void* base = nullptr;
+        CK(hipMemAddressReserve(&base, 8 * GB, 2 * MB, nullptr, 0));
+        auto one = [&](const char* what, size_t at, size_t bytes) {
+            hipMemGenericAllocationHandle_t h;
+            hipError_t e1 = hipMemCreate(&h, bytes, &prop, 0);
+            hipError_t e2 = e1 == hipSuccess ? hipMemMap((char*)base + at, bytes, 0, h, 0) : hipErrorUnknown;
+            hipError_t e3 = e2 == hipSuccess ? hipMemSetAccess((char*)base + at, bytes, &acc, 1) : hipErrorUnknown;
+            (void)hipGetLastError();
+            std::printf("{\"mode\": \"vmmmix\", \"what\": \"%s\", \"at_mb\": %zu, \"mb\": %zu, \"create\": \"%s\", \"map\": \"%s\", \"access\": \"%s\"}\n", what, at / MB,
+                        bytes / MB, hipGetErrorString(e1), hipGetErrorString(e2), hipGetErrorString(e3));
+            std::fflush(stdout);
+        };
+        one("64 MB at 0, main thread", 0, 64 * MB);
+        one("64 MB behind it, main thread", 64 * MB, 64 * MB);
+        one("512 MB behind them (offset 128 MB), main thread", 128 * MB, 512 * MB);
+        std::thread([&] { CK(hipSetDevice(0)); one("512 MB at 1 GB, another thread", 1 * GB, 512 * MB); }).join();
+        std::thread([&] { CK(hipSetDevice(0)); one("64 MB at 1.5 GB, another thread", 1536 * MB, 64 * MB); }).join();
+        std::thread([&] { CK(hipSetDevice(0)); one("512 MB at 1.5 GB + 64 MB, another thread", 1600 * MB, 512 * MB); }).join();
+        one("whole-range access over everything mapped from 0 (640 MB)", 4 * GB, 64 * MB);
+        hipError_t e = hipMemSetAccess(base, 640 * MB, &acc, 1);
+        std::printf("{\"mode\": \"vmmmix\", \"what\": \"hipMemSetAccess(base, 640 MB) over three mappings\", \"access\": \"%s\"}\n", hipGetErrorString(e));
+    } else if (mode == "stallprobe") { // what else waits while one allocation of this process is stuck inside the driver?
+        const char* label = argc > 2 ? argv[2] : "";
+        const size_t total = (size_t)std::atoi(argv[3]) * GB, chunk = 128 * MB;
+        const bool with_malloc = argc > 4 && std::atoi(argv[4]) != 0; // (a blocked hipMalloc would hide what the other calls do meanwhile)
+        void *dbuf = nullptr, *hpin = nullptr;
+        CK(hipMalloc(&dbuf, 64 * MB));
+        CK(hipHostMalloc(&hpin, 1 * MB, hipHostMallocDefault));
+        std::vector<char> hpage(1 * MB, 1);
+        touch(dbuf, 64 * MB, st);
+        std::atomic<int> state{0};
+        std::atomic<char*> vmm0{nullptr}; // the first mapped chunk: a destination inside the growing range for the main thread
+        double slowest_chunk = 0, grow_ms = 0;
+        int slowest_at = -1, n_chunks = 0;
+        std::thread helper([&] {
+            CK(hipSetDevice(0));
+            hipMemAllocationProp prop{};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = 0;
+            hipMemAccessDesc acc{};
+            acc.location = prop.location;
+            acc.flags = hipMemAccessFlagsProtReadWrite;
+            void* base = nullptr;
+            CK(hipMemAddressReserve(&base, total, 2 * MB, nullptr, 0));
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            state = 1;
+            const auto tg = clk::now();
+            std::vector<hipMemGenericAllocationHandle_t> hs;
+            for (size_t off = 0; off < total; off += chunk) {
+                const auto t0 = clk::now();
+                hipMemGenericAllocationHandle_t h;
+                CK(hipMemCreate(&h, chunk, &prop, 0));
+                CK(hipMemMap((char*)base + off, chunk, 0, h, 0));
+                CK(hipMemSetAccess((char*)base + off, chunk, &acc, 1));
+                const double ms = ms_since(t0);
+                if (ms > slowest_chunk) slowest_chunk = ms, slowest_at = (int)(off / chunk);
+                hs.push_back(h);
+                ++n_chunks;
+                if (off == 0) vmm0 = (char*)base;
+            }
+            grow_ms = ms_since(tg);
+            state = 2;
+            for (size_t k = 0; k < hs.size(); ++k) {
+                CK(hipMemUnmap((char*)base + k * chunk, chunk));
+                CK(hipMemRelease(hs[k]));
+            }
+            CK(hipMemAddressFree(base, total));
+        });
+        double mx_launch = 0, mx_h2d_page = 0, mx_h2d_pin = 0, mx_malloc = 0, mx_event = 0, mx_vmm_kernel = 0, mx_vmm_h2d = 0, mx_vmm_memset = 0, mx_vmm_d2h = 0;
+        int iters = 0;
+        hipEvent_t ev;
+        CK(hipEventCreate(&ev));
+        while (state.load() < 2) {
+            if (state.load() == 0) continue;
+            auto t0 = clk::now();
+            hipLaunchKernelGGL(k_touch, dim3(64), dim3(256), 0, st, (uint4*)dbuf, (1 * MB) / 16);
+            CK(hipStreamSynchronize(st));
+            mx_launch = std::max(mx_launch, ms_since(t0));
+            t0 = clk::now();
+            CK(hipMemcpyAsync(dbuf, hpage.data(), 1 * MB, hipMemcpyHostToDevice, st));
+            CK(hipStreamSynchronize(st));
+            mx_h2d_page = std::max(mx_h2d_page, ms_since(t0));
+            t0 = clk::now();
+            CK(hipMemcpyAsync(dbuf, hpin, 1 * MB, hipMemcpyHostToDevice, st));
+            CK(hipStreamSynchronize(st));
+            mx_h2d_pin = std::max(mx_h2d_pin, ms_since(t0));
+            t0 = clk::now();
+            CK(hipEventRecord(ev, st));
+            CK(hipEventSynchronize(ev));
+            mx_event = std::max(mx_event, ms_since(t0));
+            if (char* v = vmm0.load()) { // the same operations with the already mapped first chunk of the GROWING range as the target
+                t0 = clk::now();
+                hipLaunchKernelGGL(k_touch, dim3(64), dim3(256), 0, st, (uint4*)v, (1 * MB) / 16);
+                CK(hipStreamSynchronize(st));
+                mx_vmm_kernel = std::max(mx_vmm_kernel, ms_since(t0));
+                t0 = clk::now();
+                CK(hipMemcpyAsync(v, hpin, 1 * MB, hipMemcpyHostToDevice, st));
+                CK(hipStreamSynchronize(st));
+                mx_vmm_h2d = std::max(mx_vmm_h2d, ms_since(t0));
+                t0 = clk::now();
+                CK(hipMemsetAsync(v, 0, 1 * MB, st));
+                CK(hipStreamSynchronize(st));
+                mx_vmm_memset = std::max(mx_vmm_memset, ms_since(t0));
+                t0 = clk::now();
+                CK(hipMemcpyAsync(hpin, v, 1 * MB, hipMemcpyDeviceToHost, st));
+                CK(hipStreamSynchronize(st));
+                mx_vmm_d2h = std::max(mx_vmm_d2h, ms_since(t0));
+            }
+            if (with_malloc) {
+                t0 = clk::now();
+                void* q = nullptr;
+                CK(hipMalloc(&q, 1 * MB));
+                mx_malloc = std::max(mx_malloc, ms_since(t0));
+                CK(hipFree(q));
+            }
+            ++iters;
+        }
+        helper.join();
+        std::printf("{\"mode\": \"stallprobe\", \"label\": \"%s\", \"grow_gb\": %.1f, \"chunks\": %d, \"grow_ms\": %.1f, \"slowest_chunk_ms\": %.1f, \"slowest_chunk\": %d, "
+                    "\"main_thread_iterations\": %d, \"slowest_ms\": {\"kernel_launch_and_sync\": %.2f, \"h2d_1mb_pageable\": %.2f, \"h2d_1mb_pinned\": %.2f, "
+                    "\"event_record_and_sync\": %.2f, \"hipMalloc_1mb\": %.2f, \"kernel_on_the_growing_range\": %.2f, \"h2d_pinned_into_the_growing_range\": %.2f, "
+                    "\"memset_in_the_growing_range\": %.2f, \"d2h_from_the_growing_range\": %.2f}}\n",
+                    label, total / 1e9, n_chunks, grow_ms, slowest_chunk, slowest_at, iters, mx_launch, mx_h2d_page, mx_h2d_pin, mx_event, mx_malloc, mx_vmm_kernel,
+                    mx_vmm_h2d, mx_vmm_memset, mx_vmm_d2h);
     } else if (mode == "concurrent") {
         const char* label = argc > 2 ? argv[2] : "";
         const size_t s = (size_t)std::atoi(argv[3]) * GB;

@@ -135,6 +135,38 @@ def test_bench_record_of_a_two_rank_run():
     assert "RCCL gather to rank 0" in rec["config"]["workload"] and rec["config"]["paths_per_step"] == 3840 * 2160 * 1024
 
 
+def test_bench_record_carries_the_one_gpu_figure_of_the_same_frame(tmp_path):
+    """An N > 1 line names the committed one-GPU record of the same frame on the same kernels ("single_gpu_reference"), so that
+    scaling efficiency = value / (N x reference) is computable from the line alone; a record of another build, of another frame or
+    of several GPUs is refused with the reason, and a one-GPU line has no such key."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = bench.CONFIGS[3]
+    metric = "Mray/s (primary+secondary) at 3840x2160/1024spp"
+    rd = tmp_path / "profiles" / "round9"
+    rd.mkdir(parents=True)
+    common = dict(config_id=3, cfg=cfg, nx=3840, ny=2160, spp=1024, spp_total=1024, scaling="strong", max_depth=50, band=8, backend="nccl", steps=2,
+                  warmup=1, elapsed_max=0.5, rays_total=4e9, gather_ms=0.4, rank0={"n_paths": 10, "n_rays": 25, "n_texture_fetches": 0, "n_slices": 1,
+                                                                                   "bytes_algorithmic": 4000, "seconds_device": 1e-6, "launches": 4},
+                  profiles_root=str(tmp_path / "profiles"))
+    rec = bench.build_record(**common, world=2, per_rank=[(0.2, 4e11), (0.25, 4e11)], build_id="a" * 16)
+    assert rec["single_gpu_reference"]["value"] is None and "no profiles" in rec["single_gpu_reference"]["reason"]
+    (rd / "bench_config3.json").write_text(json.dumps({"metric": metric, "value": 5000.0, "unit": "Mray/s", "n_gpus": 1, "ms_per_step": 800.0,
+                                                       "library_build_id": "a" * 16}))
+    rec = bench.build_record(**common, world=2, per_rank=[(0.2, 4e11), (0.25, 4e11)], build_id="a" * 16)
+    ref = rec["single_gpu_reference"]
+    assert ref["value"] == 5000.0 and ref["source"] == "profiles/round9/bench_config3.json" and ref["library_build_id"] == "a" * 16
+    assert rec["value"] / (rec["n_gpus"] * ref["value"]) == 0.8  # the efficiency a reader computes
+    rec = bench.build_record(**common, world=2, per_rank=[(0.2, 4e11), (0.25, 4e11)], build_id="b" * 16)  # other kernels
+    assert rec["single_gpu_reference"]["value"] is None and "was taken on build " + "a" * 16 in rec["single_gpu_reference"]["reason"]
+    (rd / "bench_config3.json").write_text(json.dumps({"metric": metric.replace("1024spp", "256spp"), "value": 5000.0, "n_gpus": 1, "library_build_id": "a" * 16}))
+    rec = bench.build_record(**common, world=2, per_rank=[(0.2, 4e11), (0.25, 4e11)], build_id="a" * 16)
+    assert rec["single_gpu_reference"]["value"] is None and "not a one-GPU line of this frame" in rec["single_gpu_reference"]["reason"]
+    rec = bench.build_record(**common, world=1, per_rank=[(0.2, 4e11)], build_id="a" * 16)
+    assert "single_gpu_reference" not in rec
+
+
 def test_bench_first_frame_leg_reports_instead_of_raising():
     """bench.first_frame runs the cold frame (context + scene build + upload + first render) in a process of its own; where that
     process cannot render (no GPU here) the bench line gets an "error" entry under "first_frame", never an exception or a hang."""
