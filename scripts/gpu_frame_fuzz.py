@@ -62,6 +62,7 @@ def explain_list_walk(scene, nx, ny, spp, depth, pseed):
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+far_exp = float(sys.argv[3]) if len(sys.argv) > 3 else 6.0  # general scenes are moved up to 10^far_exp units out
 rt.register_default_images()
 r = rt.Renderer(0)
 u = np.uint32
@@ -71,7 +72,7 @@ for seed in range(first, first + n_seeds):
     rng = np.random.default_rng(10_000 + seed)
     kind = "general" if rng.random() < 0.5 else "spheres"
     far = kind == "general" and rng.random() < 0.5  # the general scene moved 1e3 .. 1e6 units out as a whole
-    off = rng.normal(size=3) * 10.0 ** rng.uniform(3, 6) if far else None
+    off = rng.normal(size=3) * 10.0 ** rng.uniform(3, far_exp) if far else None
     scene = (T._random_scene(rt, 1000 + int(rng.integers(0, 100000)), offset=off) if kind == "general"
              else grid_fuzz_scene(rt, int(rng.integers(0, 100000)))[0])
     if far:
