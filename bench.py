@@ -74,7 +74,7 @@ def _latest_profile(pattern, workload_key, build_id):
     return best if best else (None, stale)
 
 
-def pmc_traffic(workload_key, build_id):
+def pmc_traffic(workload_key, build_id, bytes_per_launch=None):
     """HBM bytes per trace-step launch from the committed PMC pass of this same command on this same build
     (scripts/collect_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, corrections calibrated in
     profiles/round3/fetch_calibration.json).  bench.py cannot profile itself, so the number comes from profiles/;
@@ -82,6 +82,10 @@ def pmc_traffic(workload_key, build_id):
     p, t = _latest_profile("traffic*.json", workload_key, build_id)
     if not p:
         return None, t
+    # per launch of THIS run: the PMC pass profiles the first frame of a process, which may take its samples in more slices (and
+    # launches) than a steady frame does — the ratio to the algorithmic bytes is what carries over
+    if bytes_per_launch and t.get("traffic_over_algorithmic"):
+        return round(t["traffic_over_algorithmic"] * bytes_per_launch, 1), os.path.relpath(p, ROOT)
     return t["trace_step_bytes_per_launch"], os.path.relpath(p, ROOT)
 
 
@@ -375,7 +379,7 @@ def build_record(*, config_id, cfg, nx, ny, spp, spp_total, scaling, max_depth, 
     trace_s, trace_bytes = per_rank[0] if per_rank else (0.0, 0)
     achieved, frac = trace_roofline(trace_bytes, trace_s) if rendered else (None, None)
     launches = r0.get("launches", 0)
-    traffic, traffic_src = pmc_traffic(workload, build_id) if rendered else (None, None)
+    traffic, traffic_src = pmc_traffic(workload, build_id, trace_bytes / max(launches, 1)) if rendered else (None, None)
     out = {
         # BASELINE.json's metric is quoted on config 2; the other configs carry their own frame in the label
         "metric": f"Mray/s (primary+secondary) at {nx}x{ny}/{spp_total}spp",
@@ -560,6 +564,9 @@ def main():
 
     rt.register_default_images()
     renderer = rt.Renderer(device_index)  # raises if librtow_mi355x.so is missing
+    # the frame is known before the world is built (main.rs:64-67): the context requests its work buffers meanwhile
+    renderer.prepare(rt.make_params(nx, ny, spp_total, max_depth=args.max_depth, seed=95, shard_band=args.band, shard_count=world,
+                                    shard_id=rank, spp_slice=args.spp_slice))
     # a dedicated non-default stream: the library's launches, its HIP events and the RCCL gather are
     # all ordered on it (stream handle 0 would make the library fall back to its own stream); the band
     # buffer is allocated on that stream too

@@ -1,12 +1,12 @@
 """Rewrites the generated block of DESIGN.md section 6 (between `<!-- numbers:begin -->` and `<!-- numbers:end -->`) and the
-headline sentence of README.md from profiles/round5 (run after scripts/gpu_round_profiles.sh + copying its files there), so
+headline sentence of README.md from profiles/round6 (run after scripts/gpu_round_profiles.sh + copying its files there), so
 that no current number in those files is typed by hand."""
 import json
 import os
 import re
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(root, "profiles", "round5") + "/"
+P = os.path.join(root, "profiles", "round6") + "/"
 
 
 def sp(x):
@@ -17,7 +17,7 @@ b2 = json.load(open(P + "bench_config2.json"))
 t2 = json.load(open(P + "traffic_config2.json")) if os.path.exists(P + "traffic_config2.json") else None
 v2 = json.load(open(P + "valu_config2.json"))["kernels"] if os.path.exists(P + "valu_config2.json") else None
 cb = b2["cpu_baseline"]
-block = (f"| round 5: the depth-0 launch decided inside the frame, two chains on two hardware queues, hit-record loads in one round trip, division / square root / `near_one` at the cost their operands need (another box: ±2 %) | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
+block = (f"| round 6: the same kernels (two experiments on them filed, section 9); all device memory of a context in one range grown by a helper thread (another box: ±2 %) | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
          f"{100 * b2['roofline']['frac']:.1f} % |\n"
          f"| CPU oracle, stream order + BVH, {cb['cores']} host cores (EPYC 9575F), the faster of the portable and the `-march=native` build | "
          f"{cb['value']:.1f} | — | — |\n\n"
@@ -34,15 +34,18 @@ if t2:
               f"{t2['traffic_over_algorithmic']:.3f} x the algorithmic bytes.  ")
 block += (f"Handed to the host as the reference's output is (f32 frame + flipped RGB8 through `rt_render` into page-locked memory): "
           f"{sp(b2['value_host_inclusive'])} Mray/s ({100 * (b2['value_host_inclusive'] / b2['value'] - 1):+.1f} %; `value_host_inclusive`, never `value`).  ")
-ff = b2.get("first_frame") or {}
-if ff.get("first_frame_ms"):
-    pm = ff["parts_ms"]
-    block += (f"What the reference's own timer covers — one frame per process (`main.rs:62-129`) — in a process of its own: `first_frame_ms` = {ff['first_frame_ms']:.0f} ms "
-              f"(`rt_ctx_create` {pm['rt_ctx_create']:.0f}, host scene build {pm['scene_build_host']:.0f}, `rt_scene_upload` {pm['rt_scene_upload']:.0f}, first `rt_render` {pm['first_rt_render']:.0f} "
-              f"of which {ff['first_render_device_ms']:.1f} ms on the device against {ff['second_render_device_ms']:.1f} for the second frame, {ff['first_render_trace_launches']} trace launches both), "
-              f"`alloc_bytes` = {ff['alloc_bytes'] / 1e9:.1f} GB.  (The first `rt_render` is 55-59 ms on a quiet box; when processes before it have just freed tens of GB "
-              f"its first `hipMalloc` waits for the driver — 0.5 s after the profile script's rocprofv3 runs, 3.9 s for the fifth fresh process in a row: "
-              f"`profiles/round5/first_frame_five_fresh_processes.txt`; the device time of the frame does not change.)\n")
+ff, fq = b2.get("first_frame") or {}, b2.get("first_frame_quiet_device") or {}
+if ff.get("first_frame_ms") and fq.get("first_frame_ms"):
+    def parts(f):
+        pm = f["parts_ms"]
+        return (f"{f['first_frame_ms']:.0f} ms (`rt_ctx_create` {pm['rt_ctx_create']:.0f}, host scene build {pm['scene_build_host']:.0f}, `rt_scene_upload` {pm['rt_scene_upload']:.0f}, "
+                f"first `rt_render` {pm['first_rt_render']:.0f} in {f['first_render_slices']} slice(s) — {f['first_render_device_ms']:.1f} ms on the device against "
+                f"{f['second_render_device_ms']:.1f} for the second frame, which takes {pm['second_rt_render']:.0f} ms in all — slowest chunk of the pool "
+                f"{f['first_render_parts_ms'].get('pool_slowest_chunk_ms', 0):.0f} ms)")
+    block += (f"What the reference's own timer covers — one frame per process (`main.rs:62-129`), here with `rt_prepare` before the scene is built — in a process of its own, "
+              f"twice: before the bench process has touched the GPU `first_frame_ms` = {parts(fq)}; after the timed steps, beside the bench process and its "
+              f"{ff['alloc_bytes'] / 1e9:.0f} GB, {parts(ff)}.  `alloc_bytes` = {ff['alloc_bytes'] / 1e9:.1f} GB.  (One request in a few waits 3-6 s inside the driver on this machine, "
+              f"section 2: a first frame that meets it on one of the first chunks of its pool takes that long, as in `profiles/round6/first_chunk_stalls.txt`; met later it costs slices.)\n")
 else:
     block += "\n"
 p = os.path.join(root, "DESIGN.md")
