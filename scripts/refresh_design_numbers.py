@@ -17,11 +17,11 @@ b2 = json.load(open(P + "bench_config2.json"))
 t2 = json.load(open(P + "traffic_config2.json")) if os.path.exists(P + "traffic_config2.json") else None
 v2 = json.load(open(P + "valu_config2.json"))["kernels"] if os.path.exists(P + "valu_config2.json") else None
 cb = b2["cpu_baseline"]
-block = (f"| round 6: the same kernels (two experiments on them filed, section 9); all device memory of a context in one range grown by a helper thread (another box: ±2 %) | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
+block = (f"| round 6: the same kernels (two experiments on them filed, section 9); all device memory of a context in one range grown by a helper thread.  Three leases of this build: 43.92 / 44.33 / 45.50 ms per frame — boxes differ by that much; the committed line is the last one taken | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
          f"{100 * b2['roofline']['frac']:.1f} % |\n"
          f"| CPU oracle, stream order + BVH, {cb['cores']} host cores (EPYC 9575F), the faster of the portable and the `-march=native` build | "
          f"{cb['value']:.1f} | — | — |\n\n"
-         f"(`profiles/round5/bench_config2.json`: `python bench.py --steps 20 --warmup 5`, build `{b2['library_build_id']}`; CPU builds probed: "
+         f"(`profiles/round6/bench_config2.json`: `python bench.py --steps 20 --warmup 5`, build `{b2['library_build_id']}`; CPU builds probed: "
          + "; ".join(f"{k.split(' (')[0]}: {v} Mray/s at 1 spp" for k, v in cb.get("builds_probed", {}).items()) + ".)\n\n"
          f"`roofline.frac` = algorithmic bytes of the trace step / its device time / 8 TB/s = {sp(b2['roofline']['achieved'])} GB/s / 8 000; whole path "
          f"(96 B / ray + 24 B / path) {b2['whole_path']['hbm_frac']:.3f}.  The kernels are bound by vector issue (section 4), so the honest companion is the VALU "
@@ -30,7 +30,7 @@ if v2:
     block += ": " + ", ".join(f"`{k}` issues {x['issue_frac']:.2f} of the measured peak at {x['lane_util']:.2f} lane utilisation" for k, x in v2.items())
 block += ") and the instruction count.  "
 if t2:
-    block += (f"Measured traffic (PMC, FETCH x 2 + WRITE): {sp(t2['trace_step_bytes_per_launch'] / 1e6)} MB per launch = "
+    block += (f"Measured traffic (PMC, FETCH x 2 + WRITE): {sp((b2['roofline'].get('traffic') or t2['trace_step_bytes_per_launch']) / 1e6)} MB per launch = "
               f"{t2['traffic_over_algorithmic']:.3f} x the algorithmic bytes.  ")
 block += (f"Handed to the host as the reference's output is (f32 frame + flipped RGB8 through `rt_render` into page-locked memory): "
           f"{sp(b2['value_host_inclusive'])} Mray/s ({100 * (b2['value_host_inclusive'] / b2['value'] - 1):+.1f} %; `value_host_inclusive`, never `value`).  ")
