@@ -396,8 +396,12 @@ QueueGeom queue_geom(const RtCtx* ctx, uint32_t n_max) {
 // ---- slice sizing (rt_prepare and render_impl) ----------------------------------------------------------------
 // A ray of a slice costs 100 B of work buffers (two 40 B queues, 8 B hit record, 12 B radiance slot).  Few, large slices amortise
 // the short-queue tail of the bounce loop (depths > ~12 hold a few thousand rays: config 2 measured 99 / 88 / 82 / 79.5 ms per
-// frame with 8 / 4 / 2 / 1 slices), so the library's own choice is up to 640 Mi rays (65 GiB of the 288 GB HBM) and never more
+// frame with 8 / 4 / 2 / 1 slices), so the library's own choice is up to 1 280 Mi rays (134 GB of the 288 GB HBM) and never more
 // than half of what the device has free.
+#ifndef RT_MAX_SLICE_MI_RAYS
+#define RT_MAX_SLICE_MI_RAYS 1280 // Mi rays of the largest slice the library chooses by itself (134 GB of work buffers).  640 until round 6:
+                                  // config 3 (4K, 1024 spp) in 7 slices instead of 13 is 1.6 % faster, config 5 1 % (the tail of a slice costs 3.7 ms)
+#endif
 uint32_t queue_shards(const RtCtx* ctx) { return ctx->opt[RT_OPT_QUEUE_SHARDS] ? ctx->opt[RT_OPT_QUEUE_SHARDS] : (uint32_t)ctx->n_cu * 8u; }
 size_t slice_bytes(const RtCtx* ctx, uint32_t npix, uint32_t sc) {
     const uint32_t nq = queue_shards(ctx), n_max = npix * sc;
@@ -421,7 +425,7 @@ int plan_slices(RtCtx* ctx, const RtParams* prm, uint64_t npix64, SlicePlan& pl)
     const uint32_t spp = prm->spp;
     uint32_t S = prm->spp_slice;
     pl.by_library = S == 0u;
-    if (pl.by_library) S = (uint32_t)std::max<uint64_t>(1, (640ull << 20) / npix64);
+    if (pl.by_library) S = (uint32_t)std::max<uint64_t>(1, ((uint64_t)RT_MAX_SLICE_MI_RAYS << 20) / npix64);
     S = std::min(std::min(S, spp), 1u << 20); // udiv_inv (slot -> sample, pixel) wants quotients below 2^21
     if ((uint64_t)S * npix64 > 0xFFFFFF00ull) S = (uint32_t)(0xFFFFFF00ull / npix64);
     if (S == 0) return fail(ctx, RT_ERR_UNSUPPORTED, "render: shard has more than 2^32 pixels");

@@ -116,7 +116,7 @@ inline void pool_grower(WorkPool* p) {
 // started if it is not running.  A pool that stopped at the device's limit earlier tries again: memory may have come back.
 // Returns the error text of a failed reservation, or nullptr.
 inline const char* pool_request(WorkPool& p, size_t bytes) {
-    constexpr size_t RESERVE = 80ull << 30; // 640 Mi rays x 100 B + rounding: the largest slice render_impl ever asks for
+    constexpr size_t RESERVE = 160ull << 30; // RT_MAX_SLICE_RAYS x 100 B + the small buffers + rounding: the largest slice render_impl ever asks for
     if (!p.base) {
         void* va = nullptr;
         if (hipMemAddressReserve(&va, RESERVE, 2ull << 20, nullptr, 0) != hipSuccess) {

@@ -1188,12 +1188,30 @@ def _hip_memory():
             n_bytes -= sz
         return out
 
+    def leave_free(target, ptrs, piece=4 << 30):
+        """Allocates (appending to ptrs) or gives back pieces until hipMemGetInfo reports about `target` bytes free — its figure
+        trails the allocations by a moment, so this converges instead of trusting one reading."""
+        for _ in range(40):
+            time.sleep(0.05)
+            f = free_bytes()
+            if f > target + (48 << 20):
+                got = hold(min(f - target, piece), piece=min(f - target, piece))
+                if not got:
+                    piece = max(piece // 2, 8 << 20)
+                ptrs += got
+            elif f < target - (20 << 20) and ptrs:
+                assert hip.hipFree(ptrs.pop()) == 0
+                piece = 32 << 20
+            else:
+                break
+        return ptrs
+
     def release(ptrs):
         for p in ptrs:
             assert hip.hipFree(p) == 0
         ptrs.clear()
 
-    return free_bytes, hold, release
+    return free_bytes, hold, release, leave_free
 
 
 @pytest.mark.gpu
@@ -1201,7 +1219,7 @@ def test_render_under_memory_pressure(rt):
     """The work buffers take what the device can give (rt_pool.h): beside a tenant that leaves 20 GB free a 13 GB slice becomes
     several smaller ones and the frame is the same bits; with next to nothing free rt_render returns RT_ERR_NOMEM and says so,
     the same context renders a small frame in what there is and the large one once memory is back, and nothing leaks."""
-    free_bytes, hold, release = _hip_memory()
+    free_bytes, hold, release, leave_free = _hip_memory()
     scene = rt.Scene.build("sphere_scene", 16 / 9)
     big = rt.make_params(1920, 1080, 64, max_depth=50, seed=95)
     small = rt.make_params(64, 36, 4, max_depth=50, seed=95)
@@ -1217,7 +1235,7 @@ def test_render_under_memory_pressure(rt):
     r1 = r2 = None
     try:
         # ---- 20 GB free: a context may take half of it
-        tenant += hold(free_bytes() - (20 << 30))
+        leave_free(20 << 30, tenant, piece=16 << 30)
         assert abs(free_bytes() - (20 << 30)) < (1 << 30)
         r1 = rt.Renderer(0)
         r1.upload(scene)
@@ -1229,7 +1247,7 @@ def test_render_under_memory_pressure(rt):
         pool_mb = r1.render_parts()["pool_mapped_mb"]
         assert 2048 <= pool_mb <= 10 * 1024 + 512, pool_mb  # half of what was free, never more
         # ---- ~150 MB free: the large frame's small buffers (92 MB) and one sample per pixel (199 MB) do not fit
-        squeeze = hold(free_bytes() - (150 << 20), piece=4 << 30)
+        squeeze = leave_free(160 << 20, [], piece=4 << 30)
         assert (128 << 20) <= free_bytes() < (330 << 20), free_bytes()
         r2 = rt.Renderer(0)
         r2.upload(scene)
