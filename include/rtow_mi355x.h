@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 10u /* 10: rt_prepare; the test hooks moved to rtow_mi355x_debug.h (every v9 layout and prototype unchanged) */
+#define RT_ABI_VERSION 11u /* 11: RtFlatScene::med_xform (wrappers around a medium); wrapper chains of any depth, up to RT_MAX_MEDIA = 65 535 media.
+                             * 10: rt_prepare; the test hooks moved to rtow_mi355x_debug.h */
 
 /* error codes */
 #define RT_OK 0
@@ -95,10 +96,12 @@ enum RtXformType {
     RT_XF_ROTATE_Y = 1   /* param = sin_theta, cos_theta, angle_degrees, 0   hitable.rs:438-510 */
 };
 #define RT_NO_XFORM 0xFFFFFFFFu
-#define RT_MAX_XFORM_CHAIN 4u /* nesting depth the kernels support */
+/* (wrappers nest to any depth, as the trait objects do: chains of up to 4 are walked in registers, longer ones through a list
+ * that rt_scene_upload builds) */
 
 #define RT_NO_MEDIUM 0xFFFFFFFFu
-#define RT_MAX_MEDIA 32u /* the medium's random draw uses counter slot 224 + medium index of its depth block */
+#define RT_MAX_MEDIA 65535u /* a depth's block of free-path counters holds this many; the 32nd and later media of a scene are
+                             * tested together by a ray that reaches any of them, so scenes with many media are slower */
 
 #define RT_NO_TEX 0xFFFFFFFFu
 #define RT_PERLIN_POINTS 256u /* texture.rs:51 */
@@ -148,6 +151,11 @@ typedef struct RtFlatScene {
     const uint32_t* med_mat;          /* [n_media] material index (RT_MAT_ISOTROPIC) */
     const uint32_t* sph_medium;       /* [n_spheres] owning medium or RT_NO_MEDIUM; NULL = none */
     const uint32_t* rect_medium;      /* [n_rects] likewise */
+    const uint32_t* med_xform;        /* [n_media] the innermost wrapper AROUND medium i — `Translate { ptr: ConstantMedium }`,
+                                       * hitable.rs:409-416: the medium's hit() then sees the moved ray (its length, its
+                                       * rec.p = r.at(t)) and the wrapper fixes the record — or RT_NO_XFORM; NULL = none.
+                                       * The chains of the boundary's primitives continue through this wrapper (they end
+                                       * at the world like any other); wrappers INSIDE the boundary need no entry here. */
 
     /* materials */
     uint32_t n_materials;

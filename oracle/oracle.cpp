@@ -294,7 +294,9 @@ struct Rng {
  * so the value does not depend on the order in which media are visited. */
 inline float rng_medium_draw(Rng& rng, uint32_t m) {
     if (!rng.counter) return rng.xo.next_f32();
-    return (float)(ctr_draw(rng.k0, rng.k1, rng.base + 224u + m) >> 8) * (1.0f / 16777216.0f);
+    /* (media beyond the 32nd: a block of 65 536 counters per depth above 2^30, where no other draw of a path lies; base = (depth + 1) * 256) */
+    const uint32_t ctr = m < 32u ? rng.base + 224u + m : 0x40000000u + (rng.base << 8) + m;
+    return (float)(ctr_draw(rng.k0, rng.k1, ctr) >> 8) * (1.0f / 16777216.0f);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -553,13 +555,17 @@ inline void xform_fix_record(const RtFlatScene& fs, uint32_t x, const Ray& inner
     rec.p = p;
     set_face_normal(rec, inner, n); /* quirk kept: the object-space ray against the world-space normal */
 }
-/* a primitive below its chain of wrappers: ray outside-in, record inside-out */
-inline bool prim_hit_x(const RtFlatScene& fs, int i, const Ray& r, float t_min, float t_max, HitRecord& rec) {
-    uint32_t chain[RT_MAX_XFORM_CHAIN];
-    int n = 0;
-    for (uint32_t x = prim_xform(fs, i); x != RT_NO_XFORM && n < (int)RT_MAX_XFORM_CHAIN; x = fs.xf_parent[x]) chain[n++] = x;
-    if (n == 0) return prim_hit(fs, i, r, t_min, t_max, rec);
-    Ray rays[RT_MAX_XFORM_CHAIN + 1];
+/* a primitive below its chain of wrappers: ray outside-in, record inside-out.  `stop`: the wrapper the caller is already inside of
+ * (the one around the ConstantMedium whose boundary this primitive belongs to), where the chain ends for this call */
+inline bool prim_hit_x(const RtFlatScene& fs, int i, const Ray& r, float t_min, float t_max, HitRecord& rec, uint32_t stop = RT_NO_XFORM) {
+    if (prim_xform(fs, i) == stop) return prim_hit(fs, i, r, t_min, t_max, rec);
+    /* any depth of nesting, as the trait objects allow (hitable.rs:404-520); the buffers are per thread and keep their capacity */
+    thread_local std::vector<uint32_t> chain;
+    thread_local std::vector<Ray> rays;
+    chain.clear();
+    for (uint32_t x = prim_xform(fs, i); x != stop && x != RT_NO_XFORM; x = fs.xf_parent[x]) chain.push_back(x);
+    const int n = (int)chain.size();
+    rays.resize((size_t)n + 1);
     rays[n] = r;
     for (int k = n - 1; k >= 0; --k) rays[k] = xform_ray(fs, chain[k], rays[k + 1]);
     if (!prim_hit(fs, i, rays[0], t_min, t_max, rec)) return false;
@@ -593,13 +599,14 @@ inline uint32_t prim_medium(const RtFlatScene& fs, int i) {
 }
 /* boundary.hit(r, t_min, t_max, rec): the boundary object is the list of primitives tagged with medium m
  * (a GBox's sides through its wrappers, or one sphere): closest hit in list order */
+inline uint32_t medium_xform(const RtFlatScene& fs, uint32_t m) { return fs.med_xform ? fs.med_xform[m] : RT_NO_XFORM; }
 inline bool boundary_hit(const RtFlatScene& fs, uint32_t m, const Ray& r, float t_min, float t_max, HitRecord& rec) {
     HitRecord temp_rec;
     float closest_so_far = t_max;
     bool hit_anything = false;
     for (uint32_t i = 0; i < fs.n_spheres + fs.n_rects; ++i) {
         if (prim_medium(fs, (int)i) != m) continue;
-        if (prim_hit_x(fs, (int)i, r, t_min, closest_so_far, temp_rec)) {
+        if (prim_hit_x(fs, (int)i, r, t_min, closest_so_far, temp_rec, medium_xform(fs, m))) { /* r: the ray the medium received */
             hit_anything = true;
             closest_so_far = temp_rec.t;
         }
@@ -629,11 +636,26 @@ inline bool medium_hit(const RtFlatScene& fs, uint32_t m, const Ray& r, float t_
     return true; /* uv and tang keep whatever an earlier candidate left (not written, hitable.rs:574-576) */
 }
 
+/* a medium below wrappers — Translate { ptr: ConstantMedium } and so on, hitable.rs:409-416, 479-509: the medium's hit() sees the
+ * moved ray, the wrappers fix its record on the way out */
+inline bool medium_hit_x(const RtFlatScene& fs, uint32_t m, const Ray& r, float t_min, float t_max, HitRecord& rec, Rng& rng) {
+    if (medium_xform(fs, m) == RT_NO_XFORM) return medium_hit(fs, m, r, t_min, t_max, rec, rng);
+    std::vector<uint32_t> chain; /* (not the per-thread buffers of prim_hit_x: the boundary searches inside use those) */
+    for (uint32_t x = medium_xform(fs, m); x != RT_NO_XFORM; x = fs.xf_parent[x]) chain.push_back(x);
+    const int n = (int)chain.size();
+    std::vector<Ray> rays((size_t)n + 1);
+    rays[n] = r;
+    for (int k = n - 1; k >= 0; --k) rays[k] = xform_ray(fs, chain[k], rays[k + 1]);
+    if (!medium_hit(fs, m, rays[0], t_min, t_max, rec, rng)) return false;
+    for (int k = 0; k < n; ++k) xform_fix_record(fs, chain[k], rays[k], rec);
+    return true;
+}
+
 /* hitable.rs:117-132 HitableList::hit over the flat primitive list (world order). */
 /* any world entry: primitive i < n_spheres + n_rects (unless it only bounds a medium), else medium */
 inline bool entry_hit(const RtFlatScene& fs, int i, const Ray& r, float t_min, float t_max, HitRecord& rec, Rng& rng) {
     const int np = (int)(fs.n_spheres + fs.n_rects);
-    if (i >= np) return medium_hit(fs, (uint32_t)(i - np), r, t_min, t_max, rec, rng);
+    if (i >= np) return medium_hit_x(fs, (uint32_t)(i - np), r, t_min, t_max, rec, rng);
     if (prim_medium(fs, i) != RT_NO_MEDIUM) return false;
     return prim_hit_x(fs, i, r, t_min, t_max, rec);
 }

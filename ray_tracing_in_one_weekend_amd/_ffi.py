@@ -49,7 +49,7 @@ class RtFlatScene(C.Structure):
         ("n_xforms", C.c_uint32),
         ("xf_type", _u8), ("xf_param", _f), ("xf_parent", _u32), ("sph_xform", _u32), ("rect_xform", _u32),
         ("n_media", C.c_uint32),
-        ("med_neg_inv_density", _f), ("med_mat", _u32), ("sph_medium", _u32), ("rect_medium", _u32),
+        ("med_neg_inv_density", _f), ("med_mat", _u32), ("sph_medium", _u32), ("rect_medium", _u32), ("med_xform", _u32),
         ("n_materials", C.c_uint32),
         ("mat_type", _u8), ("mat_color", _f), ("mat_p0", _f), ("mat_p1", _f), ("mat_p2", _f), ("mat_p3", _f),
         ("mat_tex0", _u32), ("mat_tex1", _u32),
@@ -119,7 +119,7 @@ class RtSceneInfo(C.Structure):
         return d
 
 
-EXPECTED_ABI = 10  # RT_ABI_VERSION the struct layouts and prototypes below were written for
+EXPECTED_ABI = 11  # RT_ABI_VERSION the struct layouts and prototypes below were written for
 GPU_SYMBOLS = ["rt_abi_version", "rt_build_id", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_upload",
                "rt_shard_rows", "rt_shard_row_to_image_row", "rt_prepare", "rt_render", "rt_render_device", "rt_debug_bounce", "rt_debug_arithmetic",
                "rt_get_depth_timings", "rt_set_progress", "rt_host_alloc", "rt_host_free", "rt_debug_set_option", "rt_debug_get_option",

@@ -154,6 +154,7 @@ class Scene:
             "rect_xform": arr(fs.rect_xform, fs.n_rects, np.uint32),
             "med_neg_inv_density": arr(fs.med_neg_inv_density, fs.n_media, np.float32), "med_mat": arr(fs.med_mat, fs.n_media, np.uint32),
             "sph_medium": arr(fs.sph_medium, ns, np.uint32), "rect_medium": arr(fs.rect_medium, fs.n_rects, np.uint32),
+            "med_xform": arr(fs.med_xform, fs.n_media, np.uint32),
             "mat_type": arr(fs.mat_type, nm, np.uint8), "mat_color": arr(fs.mat_color, 3 * nm, np.float32),
             "mat_p0": arr(fs.mat_p0, nm, np.float32), "mat_p1": arr(fs.mat_p1, nm, np.float32),
             "mat_p2": arr(fs.mat_p2, nm, np.float32), "mat_p3": arr(fs.mat_p3, nm, np.float32),

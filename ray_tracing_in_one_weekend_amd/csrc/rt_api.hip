@@ -72,6 +72,7 @@ struct RtCtx {
     size_t isect_lds = 0;      // k_intersect: nodes + geometry (when they fit) + stack levels + counters
     bool bvh_in_lds = false;   // false: the tree is traversed out of HBM/L2, only the stacks are in LDS
     bool general_lds = false;  // k_intersect<.., GLDS>: the wrapper / medium tables of a general scene are staged in LDS
+    bool nest = false;         // k_intersect<.., NEST>: a wrapper chain deeper than RT_MAX_CHAIN, more than 32 media or a wrapper around a medium (rt_device.h)
     bool general_kernels = false; // the general instantiations (rectangles, wrappers, media — or RT_OPT_GENERAL_KERNELS at upload)
     bool use_grid = false;     // sphere-only scene with a uniform grid (rt_grid.h): depth >= 1 runs k_intersect_grid
     GridParams grid{};
@@ -283,12 +284,17 @@ void launch_intersect(RtCtx* ctx, hipStream_t sg, bool use_bvh, bool gen, uint32
         hipLaunchKernelGGL(k_intersect_grid, dim3(grid), dim3(RT_BVH_BLOCK), ctx->grid_lds, sg, ctx->grid, b.qi.a, b.qi.b, b.qhit, b.cin, ip);
         return;
     }
-#define RT_LAUNCH_ISECT(G, R, N, T)                                                                                    \
-    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R, N, T>), dim3(grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, sg, ctx->ds, \
+#define RT_LAUNCH_ISECT_X(G, R, N, T, X)                                                                               \
+    hipLaunchKernelGGL((k_intersect<RT_BVH_BLOCK, G, R, N, T, X>), dim3(grid), dim3(RT_BVH_BLOCK), ctx->isect_lds, sg, ctx->ds, \
                        b.qi.a, b.qi.b, b.qhit, b.cin, ip, b.gpd)
+#define RT_LAUNCH_ISECT(G, R, N, T) RT_LAUNCH_ISECT_X(G, R, N, T, false)
+    // general scenes: tables in LDS or not; and (ctx->nest) the instantiation whose wrapper chains and media masks are loops
 #define RT_LAUNCH_ISECT_G(G, N)                       \
     do {                                              \
-        if (ctx->general_lds) RT_LAUNCH_ISECT(G, true, N, true); \
+        if (ctx->nest) {                              \
+            if (ctx->general_lds) RT_LAUNCH_ISECT_X(G, true, N, true, true); \
+            else RT_LAUNCH_ISECT_X(G, true, N, false, true);      \
+        } else if (ctx->general_lds) RT_LAUNCH_ISECT(G, true, N, true); \
         else RT_LAUNCH_ISECT(G, true, N, false);      \
     } while (0)
     // trees that do not fit LDS use the general instantiation (R = true works for sphere-only scenes too)
@@ -300,6 +306,7 @@ void launch_intersect(RtCtx* ctx, hipStream_t sg, bool use_bvh, bool gen, uint32
     else if (use_bvh) RT_LAUNCH_ISECT(false, false, true, false);
 #undef RT_LAUNCH_ISECT_G
 #undef RT_LAUNCH_ISECT
+#undef RT_LAUNCH_ISECT_X
     else {
         const size_t list_lds = (size_t)std::min<uint32_t>(std::max<uint32_t>(ctx->ds.n_spheres, 1u), RT_SPHERE_TILE) * sizeof(float4);
         hipLaunchKernelGGL(k_intersect_list, dim3(ip.q1 - ip.q0), dim3(256), list_lds, sg, ctx->ds, b.qi.a, b.qi.b, b.qhit, b.cin, ip, b.gpd);
@@ -312,12 +319,13 @@ void launch_shade(RtCtx* ctx, hipStream_t sg, bool gen, bool fused_lists, uint32
     // sphere geometry for the closest hit inside k_shade<GEN>
     const uint32_t n_fused = (gen && fused_lists) ? ctx->ds.n_spheres : 0u;
     const size_t shade_lds = shade_lds_bytes(ctx->ds.n_prims + ctx->ds.n_media, perlin_lds ? ctx->ds.n_perlin : 0u, n_fused, !gen && sp.sort);
-#define RT_LAUNCH_SHADE(P, G, R) \
-    hipLaunchKernelGGL((k_shade<P, G, R>), dim3(n_shards), dim3(256), shade_lds, sg, ctx->ds, b.qi, b.qhit, b.qo, b.cin, b.cout, b.rad, sp, b.totals, b.gpd)
+#define RT_LAUNCH_SHADE(P, G, R, X) \
+    hipLaunchKernelGGL((k_shade<P, G, R, X>), dim3(n_shards), dim3(256), shade_lds, sg, ctx->ds, b.qi, b.qhit, b.qo, b.cin, b.cout, b.rad, sp, b.totals, b.gpd)
 #define RT_LAUNCH_SHADE_R(P, G)        \
     do {                               \
-        if (rects) RT_LAUNCH_SHADE(P, G, true); \
-        else RT_LAUNCH_SHADE(P, G, false);      \
+        if (rects && ctx->nest) RT_LAUNCH_SHADE(P, G, true, true); \
+        else if (rects) RT_LAUNCH_SHADE(P, G, true, false); \
+        else RT_LAUNCH_SHADE(P, G, false, false);      \
     } while (0)
     if (perlin_lds && gen) RT_LAUNCH_SHADE_R(true, true);
     else if (perlin_lds) RT_LAUNCH_SHADE_R(true, false);
@@ -502,10 +510,14 @@ int rt_ctx_create(int device_id, RtCtx** out_ctx) {
             RT_ISECT_VARIANTS(false, true, true, true),   RT_ISECT_VARIANTS(true, true, true, true),
             RT_ISECT_VARIANTS(false, true, false, true),  RT_ISECT_VARIANTS(true, true, false, true),
 #undef RT_ISECT_VARIANTS
+#define RT_ISECT_VARIANTS(G, N, T) reinterpret_cast<const void*>(&k_intersect<RT_BVH_BLOCK, G, true, N, T, true>)
+            RT_ISECT_VARIANTS(false, true, false), RT_ISECT_VARIANTS(true, true, false), RT_ISECT_VARIANTS(false, false, false), RT_ISECT_VARIANTS(true, false, false),
+            RT_ISECT_VARIANTS(false, true, true),  RT_ISECT_VARIANTS(true, true, true),  RT_ISECT_VARIANTS(false, false, true),  RT_ISECT_VARIANTS(true, false, true),
+#undef RT_ISECT_VARIANTS
             reinterpret_cast<const void*>(&k_intersect_grid),
             reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, true>),
             reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, false>),
-#define RT_SHADE_VARIANTS(P, G) reinterpret_cast<const void*>(&k_shade<P, G, false>), reinterpret_cast<const void*>(&k_shade<P, G, true>)
+#define RT_SHADE_VARIANTS(P, G) reinterpret_cast<const void*>(&k_shade<P, G, false>), reinterpret_cast<const void*>(&k_shade<P, G, true>), reinterpret_cast<const void*>(&k_shade<P, G, true, true>)
             RT_SHADE_VARIANTS(true, true), RT_SHADE_VARIANTS(true, false), RT_SHADE_VARIANTS(false, true), RT_SHADE_VARIANTS(false, false),
 #undef RT_SHADE_VARIANTS
         };
@@ -604,21 +616,17 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         if (s->xf_parent[i] != RT_NO_XFORM && s->xf_parent[i] >= i)
             return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: transform parent must precede its child");
     }
-    auto chain_ok = [&](uint32_t x) {
-        uint32_t n = 0;
-        for (; x != RT_NO_XFORM; x = s->xf_parent[x]) {
-            if (x >= s->n_xforms || ++n > RT_MAX_XFORM_CHAIN) return false;
-        }
-        return true;
-    };
+    // (a parent precedes its child, so every chain ends; its length is xf_depth below: any number of nested wrappers, hitable.rs:404-520)
     for (uint32_t i = 0; i < s->n_spheres && s->sph_xform; ++i)
-        if (!chain_ok(s->sph_xform[i])) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad sphere transform chain");
+        if (s->sph_xform[i] != RT_NO_XFORM && s->sph_xform[i] >= s->n_xforms) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad sphere transform chain");
     for (uint32_t i = 0; i < s->n_rects && s->rect_xform; ++i)
-        if (!chain_ok(s->rect_xform[i])) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad rectangle transform chain");
+        if (s->rect_xform[i] != RT_NO_XFORM && s->rect_xform[i] >= s->n_xforms) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad rectangle transform chain");
     if (s->n_media > RT_MAX_MEDIA) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: more than RT_MAX_MEDIA media");
     if (s->n_media && (!s->med_neg_inv_density || !s->med_mat))
         return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: medium arrays missing");
     for (uint32_t m = 0; m < s->n_media; ++m) {
+        if (s->med_xform && s->med_xform[m] != RT_NO_XFORM && s->med_xform[m] >= s->n_xforms)
+            return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: bad wrapper around medium " + std::to_string(m));
         if (s->med_mat[m] >= s->n_materials) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: medium material out of range");
         const uint32_t mt = s->mat_type[s->med_mat[m]];
         // a medium writes neither uv nor tang (hitable.rs:574-576): materials that read them see stale record state
@@ -771,9 +779,27 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     std::vector<uint32_t> pxf(n_prims, RT_NO_XFORM);
     std::vector<float4> xparam(s->n_xforms);
     std::vector<uint2> xmeta(s->n_xforms);
+    // xf_meta[x] = (type, parent).  A chain of more than RT_MAX_CHAIN wrappers is listed once more behind the table, outermost wrapper
+    // first, as (wrapper, chain length), and xf_param[x].w holds where — 0 for a short chain (rt_device.h: the kernels walk short
+    // chains through the parent links into registers and long ones through the list).
+    uint32_t n_xf_listed = 0;
+    std::vector<uint32_t> xf_depth(s->n_xforms);
     for (uint32_t i = 0; i < s->n_xforms; ++i) {
-        xparam[i] = make_float4(s->xf_param[4 * i], s->xf_param[4 * i + 1], s->xf_param[4 * i + 2], s->xf_param[4 * i + 3]);
+        const uint32_t depth = xf_depth[i] = s->xf_parent[i] == RT_NO_XFORM ? 1u : xf_depth[s->xf_parent[i]] + 1u;
+        xparam[i] = make_float4(s->xf_param[4 * i], s->xf_param[4 * i + 1], s->xf_param[4 * i + 2], 0.0f);
         xmeta[i] = make_uint2(s->xf_type[i], s->xf_parent[i]);
+        if (depth > (uint32_t)RT_MAX_CHAIN) {
+            if ((uint64_t)s->n_xforms + n_xf_listed + depth > 0x7FFFFFFFull) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: wrapper chains too long to list");
+            xparam[i].w = fbits(s->n_xforms + n_xf_listed);
+            n_xf_listed += depth;
+        }
+    }
+    xmeta.resize((size_t)s->n_xforms + n_xf_listed);
+    for (uint32_t i = 0; i < s->n_xforms; ++i) {
+        if (xf_depth[i] <= (uint32_t)RT_MAX_CHAIN) continue;
+        uint32_t p0, k = xf_depth[i];
+        std::memcpy(&p0, &xparam[i].w, 4);
+        for (uint32_t x = i; x != RT_NO_XFORM; x = s->xf_parent[x]) xmeta[p0 + --k] = make_uint2(x, xf_depth[i]);
     }
     std::vector<float4> world_sphere(s->n_spheres); // instanced spheres: centre and radius in world space (culling only)
     for (uint32_t i = 0; i < n_prims; ++i) {
@@ -829,7 +855,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     std::vector<uint32_t> pmed(n_prims, RT_NO_MEDIUM), med_prims;
     std::vector<uint2> med_range(s->n_media);
     std::vector<float> med_nid(s->n_media);
-    std::vector<uint32_t> med_xf(s->n_media, RT_NO_XFORM);
+    std::vector<uint2> med_xf(s->n_media, make_uint2(RT_NO_XFORM, RT_NO_XFORM)); // (.x: the chain all boundary primitives share, .y: the wrapper around the medium)
     for (uint32_t i = 0; i < n_prims; ++i)
         pmed[i] = i < s->n_spheres ? (s->sph_medium ? s->sph_medium[i] : RT_NO_MEDIUM)
                                    : (s->rect_medium ? s->rect_medium[i - s->n_spheres] : RT_NO_MEDIUM);
@@ -845,20 +871,26 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
         for (uint32_t i = 0; i < n_prims; ++i)
             if (pmed[i] == m) {
                 // one wrapper chain for the whole boundary (a GBox under RotateY/Translate): medium_root moves the ray once
-                if (med_range[m].y == 0) med_xf[m] = pxf[i];
-                else if (med_xf[m] != pxf[i]) med_xf[m] = RT_MED_XF_MIXED;
+                if (med_range[m].y == 0) med_xf[m].x = pxf[i];
+                else if (med_xf[m].x != pxf[i]) med_xf[m].x = RT_MED_XF_MIXED;
+                if (s->med_xform && s->med_xform[m] != RT_NO_XFORM) { // the wrapper around the medium lies on the chain of every boundary primitive
+                    uint32_t x = pxf[i];
+                    while (x != RT_NO_XFORM && x != s->med_xform[m]) x = s->xf_parent[x];
+                    if (x == RT_NO_XFORM) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: the wrapper around medium " + std::to_string(m) + " is not on the chain of its boundary primitive " + std::to_string(i));
+                }
                 med_prims.push_back(i);
                 ++med_range[m].y;
                 for (int k = 0; k < 3; ++k) mb.mn[k] = std::min(mb.mn[k], pboxes[i].mn[k]), mb.mx[k] = std::max(mb.mx[k], pboxes[i].mx[k]);
             }
         if (med_range[m].y == 0) return fail(ctx, RT_ERR_INVALID, "rt_scene_upload: medium " + std::to_string(m) + " has no boundary primitives");
+        if (s->med_xform) med_xf[m].y = s->med_xform[m];
         if (med_range[m].y > RT_MED_COUNT_MASK) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: medium " + std::to_string(m) + " has too many boundary primitives");
         {   // boundaries whose two searches are answered from one evaluation of their primitives (medium_root, rt_kernels.h)
             bool all_rects = true;
             for (uint32_t k = 0; k < med_range[m].y; ++k) all_rects = all_rects && med_prims[med_range[m].x + k] >= s->n_spheres;
             uint32_t kind = 0u;
-            if (med_xf[m] != RT_MED_XF_MIXED && all_rects && med_range[m].y <= 6u) kind = RT_MED_KIND_RECTS;
-            else if (med_xf[m] != RT_MED_XF_MIXED && med_range[m].y == 1u && med_prims[med_range[m].x] < s->n_spheres) kind = RT_MED_KIND_SPHERE;
+            if (med_xf[m].x != RT_MED_XF_MIXED && all_rects && med_range[m].y <= 6u) kind = RT_MED_KIND_RECTS;
+            else if (med_xf[m].x != RT_MED_XF_MIXED && med_range[m].y == 1u && med_prims[med_range[m].x] < s->n_spheres) kind = RT_MED_KIND_SPHERE;
             if (ctx->opt[RT_OPT_MEDIUM_SEARCH] == 1u) kind = 0u; // test hook: the two searches as the reference makes them
             med_range[m].y |= kind << 24;
         }
@@ -935,6 +967,10 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     ds.n_bvh4_nodes = (uint32_t)bvh4.id.size();
     ds.n_entries = (uint32_t)eboxes.size();
     ds.n_med_prims = (uint32_t)med_prims.size();
+    ds.n_xf_listed = n_xf_listed;
+    // what only the NEST instantiations of k_intersect evaluate (rt_device.h): a listed chain, the media of mask bit 31, a wrapper around a medium
+    ctx->nest = n_xf_listed > 0 || s->n_media > 32u;
+    for (uint32_t m = 0; m < s->n_media && s->med_xform; ++m) ctx->nest = ctx->nest || s->med_xform[m] != RT_NO_XFORM;
     {   // rays whose slab slack exceeds 2^-10 of the scene extent use the cancellation-free slab test (bvh_step)
         double ext2 = 0.0;
         for (int k = 0; k < 3; ++k) {

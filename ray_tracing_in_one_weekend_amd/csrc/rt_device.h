@@ -300,12 +300,14 @@ struct DevScene {
     const uint2* med_range;
     const uint32_t* med_prims;
     uint32_t n_med_prims;      // total length of med_prims
+    uint32_t n_xf_listed;      // entries behind xf_meta[n_xforms): the chains of more than RT_MAX_CHAIN wrappers, outermost first
     // world entries (BVH leaves): bounding sphere (xyz, r) and leaf id, for the primary-ray candidate lists
     uint32_t n_entries;
     const float4* ent_bs;
     const uint32_t* ent_leaf;
     float bvh_exact_eps;       // slab slack above which a ray takes the cancellation-free test (2^-10 of the scene extent)
-    const uint32_t* med_xform; // [n_media] wrapper chain shared by all boundary primitives, or RT_MED_XF_MIXED
+    const uint2* med_xform;    // [n_media] .x: wrapper chain shared by all boundary primitives, or RT_MED_XF_MIXED; .y: the innermost
+                               // wrapper AROUND the medium (RtFlatScene::med_xform) or RT_NO_XFORM_DEV
     const uint32_t* prim_medium; // [n_prims] owning medium or 0xFFFFFFFF
     uint32_t n_rects;   // axis-aligned rectangles; primitive index = n_spheres + rect index
     uint32_t n_prims;   // n_spheres + n_rects
@@ -610,6 +612,13 @@ __device__ __forceinline__ bool rect_root(float4 g0, float4 g1, V3 o, V3 d, floa
 // ---------------------------------------------------------------------------------------------
 // Instance wrappers Translate / RotateY (hitable.rs:404-520) as a per-primitive chain
 // ---------------------------------------------------------------------------------------------
+// xf_meta[x] = (type, parent).  Chains of up to RT_MAX_CHAIN wrappers (every demo scene: 2) are walked through the parent links into an
+// unrolled array.  The reference nests without limit (hitable.rs:404-520 hold an Arc<dyn Hitable>), so a deeper chain is listed once
+// more, outermost wrapper first, behind the wrapper table itself — entries xf_meta[p0 + k] = (wrapper, chain length) with p0 = the
+// bits of xf_param[x].w, 0 for a short chain (rt_scene_upload) — and walked by a loop: the same xform_ray / unwind steps in the same
+// order, so the same bits (tests: chains of up to 18 wrappers against the oracle).  NEST: kernels are compiled twice, and only
+// scenes that nest beyond what the registers hold (RtCtx::nest: a chain of more than RT_MAX_CHAIN, more media than the per-lane
+// mask has bits, wrappers AROUND a medium) run the instantiation with the loops — the others run the code they always ran.
 #define RT_NO_XFORM_DEV 0xFFFFFFFFu
 #define RT_MAX_CHAIN 4
 struct Chain {
@@ -652,6 +661,17 @@ __device__ __forceinline__ void chain_to_object(const Tables& sc, const Chain& c
     for (int k = RT_MAX_CHAIN - 1; k >= 0; --k)
         if (k < c.n) xform_ray(sc, c.id[k], o, d);
 }
+// world ray -> object ray below the innermost wrapper `xf`, whatever the depth of its chain
+template <bool NEST, class Tables>
+__device__ __forceinline__ void ray_to_object(const Tables& sc, uint32_t xf, V3& o, V3& d) {
+    const uint32_t p0 = NEST ? __float_as_uint(sc.xf_param[xf].w) : 0u;
+    if (NEST && p0 != 0u) {
+        const uint32_t depth = sc.xf_meta[p0].y;
+        for (uint32_t k = 0; k < depth; ++k) xform_ray(sc, sc.xf_meta[p0 + k].x, o, d);
+    } else {
+        chain_to_object(sc, load_chain(sc, xf), o, d);
+    }
+}
 
 // Result of one bounce for one ray.
 struct Bounce {
@@ -672,7 +692,7 @@ struct Bounce {
 struct NoPrefetch {
     __device__ __forceinline__ void operator()() const {}
 };
-template <bool RECTS, class AfterLoads = NoPrefetch>
+template <bool RECTS, class AfterLoads = NoPrefetch, bool NEST = false>
 __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro, V3 rd, int hit, float t, Rng& rng,
                                uint32_t& n_fetch, AfterLoads after_record_loads = AfterLoads()) {
     Bounce out;
@@ -691,15 +711,23 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     }
     const bool is_medium = RECTS && (uint32_t)hit >= sc.n_prims;
     const bool is_rect = RECTS && !is_medium && (uint32_t)hit >= sc.n_spheres;
-    // RECTS also stands for "general scene": the primitive may sit below Translate / RotateY wrappers.  The
+    // RECTS also stands for "general scene": the primitive or medium may sit below Translate / RotateY wrappers.  The
     // HitRecord is then built from the innermost (object-space) ray and fixed on the way out (hitable.rs:412-414,
     // 494-506); `ro`/`rd` stay the world ray that scatter() receives (main.rs:48).
     Chain chain;
     chain.n = 0;
+    uint32_t deep_n = 0u, deep_p0 = 0u; // a chain of more than RT_MAX_CHAIN wrappers: its length and its outermost-first list
     V3 wo = ro, wd = rd; // the world ray
-    if (RECTS && !is_medium) {
-        chain = load_chain(sc, sc.prim_xform[hit]);
-        chain_to_object(sc, chain, ro, rd);
+    if (RECTS && (NEST || !is_medium)) { // (a medium: the wrappers AROUND it, hitable.rs:409-416 with ptr = a ConstantMedium; those of its boundary are inside its hit())
+        const uint32_t xf = NEST && is_medium ? sc.med_xform[(uint32_t)hit - sc.n_prims].y : sc.prim_xform[hit];
+        deep_p0 = NEST && xf != RT_NO_XFORM_DEV ? __float_as_uint(sc.xf_param[xf].w) : 0u;
+        if (NEST && deep_p0 != 0u) {
+            deep_n = sc.xf_meta[deep_p0].y;
+            for (uint32_t k = 0; k < deep_n; ++k) xform_ray(sc, sc.xf_meta[deep_p0 + k].x, ro, rd);
+        } else {
+            chain = load_chain(sc, xf);
+            chain_to_object(sc, chain, ro, rd);
+        }
     }
     V3 p = ro + rd * t;                                 // math.rs:64 Ray::at
     V3 on;
@@ -745,6 +773,25 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
             }
         }
         ro = wo, rd = wd; // materials see the world ray
+    }
+    if (RECTS && NEST && deep_n) { // the same unwinding for a chain that is only listed (level k from the inside = list entry deep_n - 1 - k)
+        for (uint32_t k = 0; k < deep_n; ++k) {
+            const uint32_t x = sc.xf_meta[deep_p0 + deep_n - 1u - k].x;
+            const float4 q = sc.xf_param[x];
+            if (sc.xf_meta[x].x == 0u) {
+                p = p + v3(q.x, q.y, q.z);
+            } else {
+                const float sin_theta = q.x, cos_theta = q.y;
+                const float px = cos_theta * p.x + sin_theta * p.z, pz = -sin_theta * p.x + cos_theta * p.z;
+                const float nx = cos_theta * n.x + sin_theta * n.z, nz = -sin_theta * n.x + cos_theta * n.z;
+                p.x = px, p.z = pz, n.x = nx, n.z = nz;
+                V3 dk = wd, ok = wo; // rot_r of this wrapper: the world ray through the wrappers from the outermost one down to it
+                for (uint32_t j = 0; j < deep_n - k; ++j) xform_ray(sc, sc.xf_meta[deep_p0 + j].x, ok, dk);
+                front_face = dot(dk, n) < 0.0f;
+                n = front_face ? n : -n;
+            }
+        }
+        ro = wo, rd = wd;
     }
     // the material fields are fetched where a branch needs them (keeps the live set small)
     struct {

@@ -343,13 +343,19 @@ __device__ __forceinline__ void closest_hit_tile(const float4* s_geo, uint32_t n
 struct MediumCtx {
     uint32_t k0, k1, base;
 };
+// Counter of medium m's free-path draw at the depth whose block starts at `base` = (depth + 1) * 256 (DESIGN.md "RNG"): slots 224-255
+// of the block for the first 32 media of a scene (every scene of rounds 1-5: the same draws as before), and for the media beyond them
+// a block of 65 536 counters per depth above 2^30, where no other draw of a path lies (base < 2^21: max_depth <= 4096).
+__device__ __forceinline__ uint32_t medium_counter(uint32_t base, uint32_t m) {
+    return m < 32u ? base + 224u + m : 0x40000000u + (base << 8) + m;
+}
 // Candidate root of one geometric primitive through its wrapper chain (general scenes), geometry from `geo`
 // (spheres, then 2 float4 per rectangle; LDS in k_intersect, HBM in the list walk).
-template <class Tables>
+template <bool NEST, class Tables>
 __device__ __forceinline__ bool prim_root(const Tables& sc, const float4* geo, uint32_t s, V3 o, V3 d, float t_min,
                                           float t_max, float& th) {
     const uint32_t xf = sc.prim_xform[s];
-    if (xf != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, xf), o, d);
+    if (xf != RT_NO_XFORM_DEV) ray_to_object<NEST>(sc, xf, o, d);
     if (s < sc.n_spheres) return sphere_root(geo[s], o, d, length_squared(d), t_min, t_max, th);
     const uint32_t gi = sc.n_spheres + 2u * (s - sc.n_spheres);
     return rect_root(geo[gi], geo[gi + 1u], o, d, t_min, t_max, th);
@@ -360,14 +366,14 @@ struct ChainCache {
     uint32_t xf; // RT_NO_XFORM_DEV = empty
     V3 o, d;
 };
-template <class Tables>
+template <bool NEST, class Tables>
 __device__ __forceinline__ bool prim_root_cached(const Tables& sc, const float4* geo, uint32_t s, V3 o, V3 d, float t_min,
                                                  float t_max, ChainCache& cc, float& th) {
     const uint32_t xf = sc.prim_xform[s];
     if (xf != RT_NO_XFORM_DEV) {
         if (xf != cc.xf) {
             cc.o = o, cc.d = d;
-            chain_to_object(sc, load_chain(sc, xf), cc.o, cc.d);
+            ray_to_object<NEST>(sc, xf, cc.o, cc.d);
             cc.xf = xf;
         }
         o = cc.o, d = cc.d;
@@ -382,23 +388,23 @@ __device__ __forceinline__ bool prim_root_cached(const Tables& sc, const float4*
 #define RT_MED_COUNT_MASK 0x00FFFFFFu
 // Root of one boundary primitive for a ray that is already in the object space of the medium's common chain
 // (RAW) or still in world space (the primitive applies its own chain).
-template <bool RAW, class Tables>
+template <bool RAW, bool NEST, class Tables>
 __device__ __forceinline__ bool boundary_prim_root(const Tables& sc, const float4* geo, uint32_t s, V3 o, V3 d,
                                                    float t_min, float t_max, float& th) {
-    if (!RAW) return prim_root(sc, geo, s, o, d, t_min, t_max, th);
+    if (!RAW) return prim_root<NEST>(sc, geo, s, o, d, t_min, t_max, th);
     if (s < sc.n_spheres) return sphere_root(geo[s], o, d, length_squared(d), t_min, t_max, th);
     const uint32_t gi = sc.n_spheres + 2u * (s - sc.n_spheres);
     return rect_root(geo[gi], geo[gi + 1u], o, d, t_min, t_max, th);
 }
 // boundary.hit(r, t_min, t_max): closest accepted root over the medium's boundary primitives
-template <bool RAW, class Tables>
+template <bool RAW, bool NEST, class Tables>
 __device__ __forceinline__ bool boundary_root(const Tables& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
                                               float t_max, float& t_out) {
     const uint2 rg = sc.med_range[m];
     bool any = false;
     for (uint32_t k = 0; k < (rg.y & RT_MED_COUNT_MASK); ++k) {
         float th;
-        if (boundary_prim_root<RAW>(sc, geo, sc.med_prims[rg.x + k], o, d, t_min, t_max, th)) {
+        if (boundary_prim_root<RAW, NEST>(sc, geo, sc.med_prims[rg.x + k], o, d, t_min, t_max, th)) {
             t_max = th;
             any = true;
         }
@@ -485,14 +491,22 @@ __device__ __forceinline__ bool boundary_both_sphere(const Tables& sc, const flo
 // cannot win and the second boundary search is skipped (pure culling, no effect on the result).
 // When all boundary primitives sit below the same wrapper chain (a GBox under RotateY/Translate) the ray is
 // moved to object space once instead of once per primitive and search — the same bits either way.
-template <class Tables>
+template <bool NEST, class Tables>
 __device__ __forceinline__ bool medium_root(const Tables& sc, const float4* geo, uint32_t m, V3 o, V3 d, float t_min,
                                             float t_max, float t_cull, const MediumCtx& mc, float& t_hit) {
     float t1, t2;
-    const float ray_len = length(d); // of the world-space ray, hitable.rs:560
-    const uint32_t cx = sc.med_xform[m];
+    // r.d.length() of the ray ConstantMedium::hit receives (hitable.rs:560): the world ray, or (NEST) what the wrappers AROUND the
+    // medium make of it (a rotation changes the last bits of a length)
+    float ray_len = length(d);
+    const uint32_t fx = NEST ? sc.med_xform[m].y : RT_NO_XFORM_DEV;
+    if (NEST && fx != RT_NO_XFORM_DEV) {
+        V3 fo = o, fd = d;
+        ray_to_object<NEST>(sc, fx, fo, fd);
+        ray_len = length(fd);
+    }
+    const uint32_t cx = sc.med_xform[m].x;
     if (cx != RT_MED_XF_MIXED) {
-        if (cx != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, cx), o, d);
+        if (cx != RT_NO_XFORM_DEV) ray_to_object<NEST>(sc, cx, o, d);
         const uint2 rg = sc.med_range[m];
         const uint32_t kind = rg.y >> 24;
         if (kind == RT_MED_KIND_RECTS) {
@@ -500,21 +514,21 @@ __device__ __forceinline__ bool medium_root(const Tables& sc, const float4* geo,
         } else if (kind == RT_MED_KIND_SPHERE) {
             if (!boundary_both_sphere(sc, geo, rg, o, d, t_cull, t1, t2)) return false;
         } else {
-            if (!boundary_root<true>(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
+            if (!boundary_root<true, NEST>(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
             if (t1 > t_cull) return false;
-            if (!boundary_root<true>(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
+            if (!boundary_root<true, NEST>(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
         }
     } else {
-        if (!boundary_root<false>(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
+        if (!boundary_root<false, NEST>(sc, geo, m, o, d, -INFINITY, INFINITY, t1)) return false;
         if (t1 > t_cull) return false;
-        if (!boundary_root<false>(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
+        if (!boundary_root<false, NEST>(sc, geo, m, o, d, t1 + 0.0001f, INFINITY, t2)) return false;
     }
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return false;
     if (t1 < 0.0f) t1 = 0.0f;
     const float dist_inside_boundary = (t2 - t1) * ray_len;
-    const uint32_t r = mix32((mc.k0 ^ ((mc.base + 224u + m) * 0x9E3779B9u)) + mc.k1);
+    const uint32_t r = mix32((mc.k0 ^ ((NEST ? medium_counter(mc.base, m) : mc.base + 224u + m) * 0x9E3779B9u)) + mc.k1);
     const float xi = (float)(r >> 8) * (1.0f / 16777216.0f);
     const float hit_dist = sc.med_neg_inv_density[m] * logf(xi);
     if (hit_dist > dist_inside_boundary) return false;
@@ -531,7 +545,7 @@ __device__ __forceinline__ void closest_hit_rects(const DevScene& sc, V3 o, V3 d
         if (sc.prim_medium[sc.n_spheres + r] != RT_NO_XFORM_DEV) continue;
         V3 po = o, pd = d;
         const uint32_t xf = sc.prim_xform[sc.n_spheres + r];
-        if (xf != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, xf), po, pd);
+        if (xf != RT_NO_XFORM_DEV) ray_to_object<true>(sc, xf, po, pd);
         if (rect_root(sc.rect_geo[2u * r], sc.rect_geo[2u * r + 1u], po, pd, 1e-3f, tbest, th)) {
             tbest = th;
             hit = (int)(sc.n_spheres + r);
@@ -539,7 +553,7 @@ __device__ __forceinline__ void closest_hit_rects(const DevScene& sc, V3 o, V3 d
     }
     for (uint32_t m = 0; m < sc.n_media; ++m) {
         float th;
-        if (medium_root(sc, sc.prim_geo, m, o, d, 1e-3f, tbest, tbest, mc, th)) {
+        if (medium_root<true>(sc, sc.prim_geo, m, o, d, 1e-3f, tbest, tbest, mc, th)) {
             tbest = th;
             hit = (int)(sc.n_prims + m);
         }
@@ -552,7 +566,7 @@ __device__ __forceinline__ void closest_hit_spheres_general(const DevScene& sc, 
         if (sc.prim_medium[s] != RT_NO_XFORM_DEV) continue;
         V3 po = o, pd = d;
         const uint32_t xf = sc.prim_xform[s];
-        if (xf != RT_NO_XFORM_DEV) chain_to_object(sc, load_chain(sc, xf), po, pd);
+        if (xf != RT_NO_XFORM_DEV) ray_to_object<true>(sc, xf, po, pd);
         if (sphere_root(sc.sph_geo[s], po, pd, length_squared(pd), 1e-3f, tbest, th)) {
             tbest = th;
             hit = (int)s;
@@ -587,7 +601,7 @@ struct GenTables {
     const uint32_t* prim_xform;
     const uint2* med_range;
     const uint32_t* med_prims;
-    const uint32_t* med_xform;
+    const uint2* med_xform;
     const float* med_neg_inv_density;
     uint32_t n_spheres, n_prims;
 };
@@ -596,18 +610,19 @@ __device__ __forceinline__ GenTables tables_of(const DevScene& sc) {
                      sc.n_spheres, sc.n_prims};
 }
 __host__ __device__ inline size_t general_lds_bytes(const DevScene& sc) {
-    return ((size_t)sc.n_xforms * 24u + (size_t)sc.n_prims * 4u + (size_t)sc.n_media * 16u + (size_t)sc.n_med_prims * 4u + 31u) & ~(size_t)15u;
+    return ((size_t)sc.n_xforms * 24u + (size_t)sc.n_xf_listed * 8u + (size_t)sc.n_prims * 4u + (size_t)sc.n_media * 20u + (size_t)sc.n_med_prims * 4u + 31u) & ~(size_t)15u;
 }
 template <int BLOCK>
 __device__ __forceinline__ GenTables stage_general(const DevScene& sc, char* smem) {
     float4* xp = reinterpret_cast<float4*>(smem);
-    uint2* xm = reinterpret_cast<uint2*>(xp + sc.n_xforms);
-    uint2* mr = xm + sc.n_xforms;
-    uint32_t* px = reinterpret_cast<uint32_t*>(mr + sc.n_media);
+    uint2* xm = reinterpret_cast<uint2*>(xp + sc.n_xforms); // (with the lists of the chains deeper than RT_MAX_CHAIN behind it, rt_device.h)
+    uint2* mr = xm + sc.n_xforms + sc.n_xf_listed;
+    uint2* mx = mr + sc.n_media;
+    uint32_t* px = reinterpret_cast<uint32_t*>(mx + sc.n_media);
     uint32_t* mp = px + sc.n_prims;
-    uint32_t* mx = mp + sc.n_med_prims;
-    float* md = reinterpret_cast<float*>(mx + sc.n_media);
-    for (uint32_t i = threadIdx.x; i < sc.n_xforms; i += BLOCK) xp[i] = sc.xf_param[i], xm[i] = sc.xf_meta[i];
+    float* md = reinterpret_cast<float*>(mp + sc.n_med_prims);
+    for (uint32_t i = threadIdx.x; i < sc.n_xforms; i += BLOCK) xp[i] = sc.xf_param[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_xforms + sc.n_xf_listed; i += BLOCK) xm[i] = sc.xf_meta[i];
     for (uint32_t i = threadIdx.x; i < sc.n_media; i += BLOCK) mr[i] = sc.med_range[i], mx[i] = sc.med_xform[i], md[i] = sc.med_neg_inv_density[i];
     for (uint32_t i = threadIdx.x; i < sc.n_prims; i += BLOCK) px[i] = sc.prim_xform[i];
     for (uint32_t i = threadIdx.x; i < sc.n_med_prims; i += BLOCK) mp[i] = sc.med_prims[i];
@@ -663,7 +678,7 @@ __device__ __forceinline__ BvhLds stage_bvh(const DevScene& sc, char* smem) {
 
 // Exact test of world entry `s` (a BVH leaf or an entry of a primary-ray candidate list) and the order-independent
 // accept.  Sphere-only scenes: Sphere::hit roots (hitable.rs:75-91).
-template <bool RECTS>
+template <bool RECTS, bool NEST = RECTS>
 __device__ __forceinline__ void leaf_test(const BvhLds& L, int s, V3 o, V3 d, float a, uint32_t& pend, float& tbest,
                                           int& hit, ChainCache* cc = nullptr) {
     float th;
@@ -678,11 +693,11 @@ __device__ __forceinline__ void leaf_test(const BvhLds& L, int s, V3 o, V3 d, fl
         // noted in `pend` and tested after the traversal (media_step), when the lanes of the wave do so
         // together.  The winner rule is order-independent, so the result is the same.
         if ((uint32_t)s >= L.gt.n_prims) {
-            pend |= 1u << ((uint32_t)s - L.gt.n_prims);
+            pend |= 1u << (NEST ? min((uint32_t)s - L.gt.n_prims, 31u) : (uint32_t)s - L.gt.n_prims); // NEST, bit 31: "one of the media from 31 on" (media_step)
             ok = false;
         } else {
-            ok = cc ? prim_root_cached(L.gt, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, *cc, th)
-                    : prim_root(L.gt, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
+            ok = cc ? prim_root_cached<NEST>(L.gt, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, *cc, th)
+                    : prim_root<NEST>(L.gt, L.geo, (uint32_t)s, o, d, 1e-3f, RT_FLT_MAX, th);
         }
     }
     if (ok && (th < tbest || (th == tbest && s > hit))) {
@@ -729,7 +744,7 @@ struct SlabPlanes {
 // (24 of the ~120 vector instructions of a node step) go away.  Only the fma form relies on it — `exact` rays (inv
 // infinite or NaN among them, see k_intersect) still order the two distances with min / max, which does not care which
 // array a value came from.
-template <int BLOCK, bool RECTS, bool SORTED = false>
+template <int BLOCK, bool RECTS, bool SORTED = false, bool NEST = RECTS>
 __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, float iy, float iz, float nox, float noy,
                                          float noz, float eps, bool exact, float a, uint32_t& pend, int& cur, int& sp,
                                          float& tbest, int& hit, const SlabPlanes* sp6 = nullptr) {
@@ -799,7 +814,7 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
             const int s = (int)(lq0 & 0xFFFFu) - 1;
             lq0 = (lq0 >> 16) | (lq1 << 16);
             lq1 >>= 16;
-            leaf_test<RECTS>(L, s, o, d, a, pend, tbest, hit, RECTS ? &cc : nullptr);
+            leaf_test<RECTS, NEST>(L, s, o, d, a, pend, tbest, hit, RECTS ? &cc : nullptr);
         }
         if (best != (int)0x80000000) {
             cur = best;
@@ -812,15 +827,23 @@ __device__ __forceinline__ bool bvh_step(const BvhLds& L, V3 o, V3 d, float ix, 
     return false;
 }
 // Tests the lowest pending medium of this lane against the best hit so far; returns true when none is left.
-__device__ __forceinline__ bool media_step(const BvhLds& L, V3 o, V3 d, const MediumCtx& mc, uint32_t& pend, float& tbest,
-                                           int& hit) {
-    const uint32_t m = (uint32_t)__ffs((int)pend) - 1u;
+// The mask has a bit for each of the first 31 media of a scene.  Bit 31 stands for all the others together: a lane whose walk met one
+// of them tests every medium from 31 on — the boundary searches of a medium the ray does not reach find nothing, and the winner rule
+// does not depend on the order — so a scene may hold any number of media (the reference's world is a Vec, hitable.rs:104-105) and
+// only those with more than 31 pay for it.
+template <bool NEST>
+__device__ __forceinline__ bool media_step(const BvhLds& L, V3 o, V3 d, const MediumCtx& mc, uint32_t n_media, uint32_t& pend,
+                                           float& tbest, int& hit) {
+    const uint32_t m0 = (uint32_t)__ffs((int)pend) - 1u;
     pend &= pend - 1u;
-    const int s = (int)(L.gt.n_prims + m);
-    float th;
-    if (medium_root(L.gt, L.geo, m, o, d, 1e-3f, RT_FLT_MAX, tbest, mc, th) && (th < tbest || (th == tbest && s > hit))) {
-        tbest = th;
-        hit = s;
+    const uint32_t m1 = !NEST || m0 < 31u ? m0 + 1u : n_media;
+    for (uint32_t m = m0; m < m1; ++m) { // (one trip unless NEST)
+        const int s = (int)(L.gt.n_prims + m);
+        float th;
+        if (medium_root<NEST>(L.gt, L.geo, m, o, d, 1e-3f, RT_FLT_MAX, tbest, mc, th) && (th < tbest || (th == tbest && s > hit))) {
+            tbest = th;
+            hit = s;
+        }
     }
     return pend == 0u;
 }
@@ -839,7 +862,7 @@ struct IntersectParams {
 // 1024-thread workgroups (8 waves per SIMD) share a CU and hide each other's dependent node fetches
 // — measured +15 % on cornell_box and +20 % on final_scene against 7 waves = one workgroup.
 // GEN (depth 0): the ray is regenerated from its queue position instead of being loaded.
-template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES, bool GLDS>
+template <int BLOCK, bool GEN, bool RECTS, bool LDS_NODES, bool GLDS, bool NEST = false>
 __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float4* __restrict__ qa,
                                                      const float4* __restrict__ qb,
                                                      float2* __restrict__ qh, const uint32_t* __restrict__ in_counts,
@@ -951,13 +974,13 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
                 if (GEN && has && (list.x & 0xFFFFu) != RT_LIST_OVERFLOW) {
                     // primary ray of a pixel with a candidate list (k_primary_lists): the listed entries instead of the tree
                     const uint32_t n_list = list.x & 0xFFFFu;
-                    if (n_list > 0u) leaf_test<RECTS>(L, (int)(list.x >> 16), o, d, a, pend, tbest, hit);
-                    if (n_list > 1u) leaf_test<RECTS>(L, (int)(list.y & 0xFFFFu), o, d, a, pend, tbest, hit);
-                    if (n_list > 2u) leaf_test<RECTS>(L, (int)(list.y >> 16), o, d, a, pend, tbest, hit);
-                    if (n_list > 3u) leaf_test<RECTS>(L, (int)(list.z & 0xFFFFu), o, d, a, pend, tbest, hit);
-                    if (n_list > 4u) leaf_test<RECTS>(L, (int)(list.z >> 16), o, d, a, pend, tbest, hit);
-                    if (n_list > 5u) leaf_test<RECTS>(L, (int)(list.w & 0xFFFFu), o, d, a, pend, tbest, hit);
-                    if (n_list > 6u) leaf_test<RECTS>(L, (int)(list.w >> 16), o, d, a, pend, tbest, hit);
+                    if (n_list > 0u) leaf_test<RECTS, NEST>(L, (int)(list.x >> 16), o, d, a, pend, tbest, hit);
+                    if (n_list > 1u) leaf_test<RECTS, NEST>(L, (int)(list.y & 0xFFFFu), o, d, a, pend, tbest, hit);
+                    if (n_list > 2u) leaf_test<RECTS, NEST>(L, (int)(list.y >> 16), o, d, a, pend, tbest, hit);
+                    if (n_list > 3u) leaf_test<RECTS, NEST>(L, (int)(list.z & 0xFFFFu), o, d, a, pend, tbest, hit);
+                    if (n_list > 4u) leaf_test<RECTS, NEST>(L, (int)(list.z >> 16), o, d, a, pend, tbest, hit);
+                    if (n_list > 5u) leaf_test<RECTS, NEST>(L, (int)(list.w & 0xFFFFu), o, d, a, pend, tbest, hit);
+                    if (n_list > 6u) leaf_test<RECTS, NEST>(L, (int)(list.w >> 16), o, d, a, pend, tbest, hit);
                     if (RECTS && pend) {
                         trav = false; // its media are tested in the media phase below
                     } else {
@@ -976,14 +999,14 @@ __global__ __launch_bounds__(BLOCK, 8) void k_intersect(DevScene sc, const float
             // media phase: when no lane of the wave has tree work left, or half the wave is waiting
             const unsigned long long waiting = __ballot(has && !trav);
             if (waiting && (__popcll(waiting) >= 32 || !__any(has && trav))) {
-                if (has && !trav && media_step(L, o, d, mc, pend, tbest, hit)) {
+                if (has && !trav && media_step<NEST>(L, o, d, mc, sc.n_media, pend, tbest, hit)) {
                     qh[pos] = make_float2(tbest, __int_as_float(hit));
                     has = false;
                 }
                 continue;
             }
         }
-        if (has && trav && bvh_step<BLOCK, RECTS, SORTED>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit, &planes)) {
+        if (has && trav && bvh_step<BLOCK, RECTS, SORTED, NEST>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit, &planes)) {
             if (RECTS && pend) {
                 trav = false;
             } else {
@@ -1100,7 +1123,7 @@ __host__ __device__ inline size_t shade_lds_bytes(uint32_t n_entries, uint32_t n
     b += (size_t)n_fused_spheres * 16u;
     return (b + 15u) & ~(size_t)15u;
 }
-template <bool PERLIN_LDS, bool GEN, bool RECTS>
+template <bool PERLIN_LDS, bool GEN, bool RECTS, bool NEST = false> // NEST (general scenes only): rt_device.h, wrapper chains and media as loops
 #ifndef RT_GEN_WAVES
 #define RT_GEN_WAVES 4 // waves per SIMD the depth-0 instantiations are compiled for (98 VGPR: 5 fit).  Round 2: 4 / 5 / 6 no difference.
                        // Round 3 (cheaper draws): alone on the chip, 6 (80 VGPR, 8 B of scratch) is 2.4-2.7 % faster at depth 0 on the
@@ -1336,7 +1359,7 @@ __global__ __launch_bounds__(256, GEN ? RT_GEN_WAVES : RT_SORTED_WAVES) void k_s
                     if (__float_as_int(h.y) >= (int)(sc.n_prims + sc.n_media)) __builtin_trap();
 #endif
                     Rng rng{k0, k1, depth_counter_base(tp.depth)};
-                    bo = shade<RECTS>(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch, prefetch);
+                    bo = shade<RECTS, decltype(prefetch), NEST>(sc, pt, o, d, __float_as_int(h.y), h.x, rng, n_fetch, prefetch);
                     if (bo.alive && tp.russian_roulette) { // main.rs:49-53
                         const float rr = rng.next();
                         rr_threshold = fmaxf(bo.attenuation.x, fmaxf(bo.attenuation.y, bo.attenuation.z)); // max_element
@@ -1509,7 +1532,7 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
             uint32_t pend = 0u;
             while (!bvh_step<BLOCK, true>(L, o, d, ix, iy, iz, nox, noy, noz, eps, exact, a, pend, cur, sp, tbest, hit)) {
             }
-            while (pend && !media_step(L, o, d, mc, pend, tbest, hit)) {
+            while (pend && !media_step<true>(L, o, d, mc, sc.n_media, pend, tbest, hit)) {
             }
         }
     } else {
@@ -1531,7 +1554,7 @@ __global__ __launch_bounds__(BLOCK) void k_debug_bounce(DevScene sc, uint32_t n,
     if (!active) return;
     uint32_t n_fetch = 0;
     Rng rng{in_key[2 * i], in_key[2 * i + 1], depth_counter_base(depth)};
-    Bounce bo = shade<true>(sc, PerlinTables{sc.perlin_vec, sc.perlin_perm2}, o, d, hit, tbest, rng, n_fetch);
+    Bounce bo = shade<true, NoPrefetch, true>(sc, PerlinTables{sc.perlin_vec, sc.perlin_perm2}, o, d, hit, tbest, rng, n_fetch);
     out_hit[i] = hit;
     out_t[i] = hit >= 0 ? tbest : 0.0f;
     out_rad[3 * i] = bo.radiance.x, out_rad[3 * i + 1] = bo.radiance.y, out_rad[3 * i + 2] = bo.radiance.z;

@@ -172,6 +172,7 @@ class FlatSceneBuilder {
         if (med_mat.size() >= RT_MAX_MEDIA) throw std::runtime_error("flatten: more than RT_MAX_MEDIA media");
         med_neg_inv_density.push_back(neg_inv_density);
         med_mat.push_back(mat);
+        med_xform.push_back(cur_xform); // the wrappers open at this point are AROUND the medium (hitable.rs:409-416, 479-509)
         cur_medium = (uint32_t)med_mat.size() - 1;
         return cur_medium;
     }
@@ -184,13 +185,9 @@ class FlatSceneBuilder {
         xf_parent.push_back(cur_xform);
         const uint32_t prev = cur_xform;
         cur_xform = (uint32_t)xf_type.size() - 1;
-        if (++xform_depth > RT_MAX_XFORM_CHAIN) throw std::runtime_error("flatten: more than RT_MAX_XFORM_CHAIN nested Translate/RotateY");
         return prev;
     }
-    void pop_xform(uint32_t prev) {
-        cur_xform = prev;
-        --xform_depth;
-    }
+    void pop_xform(uint32_t prev) { cur_xform = prev; }
     RtFlatScene view() const {
         RtFlatScene s;
         std::memset(&s, 0, sizeof(s));
@@ -204,7 +201,7 @@ class FlatSceneBuilder {
         s.sph_xform = sph_xform.data(), s.rect_xform = rect_xform.data();
         s.n_media = (uint32_t)med_mat.size();
         s.med_neg_inv_density = med_neg_inv_density.data(), s.med_mat = med_mat.data();
-        s.sph_medium = sph_medium.data(), s.rect_medium = rect_medium.data();
+        s.sph_medium = sph_medium.data(), s.rect_medium = rect_medium.data(), s.med_xform = med_xform.data();
         s.n_materials = (uint32_t)mat_type.size();
         s.mat_type = mat_type.data(), s.mat_color = mat_color.data();
         s.mat_p0 = mat_p0.data(), s.mat_p1 = mat_p1.data(), s.mat_p2 = mat_p2.data(), s.mat_p3 = mat_p3.data();
@@ -230,9 +227,9 @@ class FlatSceneBuilder {
     std::vector<uint8_t> xf_type;
     std::vector<float> xf_param;
     std::vector<uint32_t> xf_parent, sph_xform, rect_xform;
-    uint32_t cur_xform = RT_NO_XFORM, xform_depth = 0;
+    uint32_t cur_xform = RT_NO_XFORM;
     std::vector<float> med_neg_inv_density;
-    std::vector<uint32_t> med_mat, sph_medium, rect_medium;
+    std::vector<uint32_t> med_mat, sph_medium, rect_medium, med_xform;
     uint32_t cur_medium = RT_NO_MEDIUM;
     uint32_t visit_mult = 1; // how many times BvhNode::hit calls the object being flattened per visit (see ConstantMedium)
     std::vector<uint8_t> mat_type;

@@ -35,7 +35,7 @@ def test_gpu_library_exports_every_declared_symbol(rt):
     nm = subprocess.run(["nm", "-D", "--defined-only", rt._ffi.GPU_LIB_PATH], check=True, capture_output=True, text=True).stdout
     exported = sorted(ln.split()[-1] for ln in nm.splitlines() if re.search(r" T rt_[a-z0-9_]+$", ln))
     assert exported == names, set(exported) ^ set(names)
-    assert lib.rt_abi_version() == 10 == rt._ffi.EXPECTED_ABI
+    assert lib.rt_abi_version() == 11 == rt._ffi.EXPECTED_ABI
     assert len(lib.rt_build_id()) in (7, 16)  # "unknown" or 16 hex digits
 
 

@@ -1779,10 +1779,12 @@ def test_config2_full_size_three_searches_agree(rt, renderer):
     assert 2.5 < sa.n_rays / sa.n_paths < 2.6
 
 
-def _random_scene(rt, seed, offset=None):
+def _random_scene(rt, seed, offset=None, nesting=False):
     """A seeded random scene through the piecewise API: spheres, rectangles and boxes, some below Translate / RotateY
     wrappers, some bounding a ConstantMedium, with every material and texture kind.  `offset`: the same scene moved there as a
-    whole — one more Translate around every object, and the camera (scripts/gpu_frame_fuzz.py: fp32 far from the origin)."""
+    whole — one more Translate around every object, and the camera (scripts/gpu_frame_fuzz.py: fp32 far from the origin).
+    `nesting`: what the reference's object model allows beyond its five demo scenes (hitable.rs:404-588 hold `Arc<dyn Hitable>`):
+    3-9 wrappers around every object, 33-47 media, half of them with 3-9 more wrappers AROUND the ConstantMedium itself."""
     rng = np.random.default_rng(seed)
     f = rt._ffi
     s = rt.Scene.new()
@@ -1801,7 +1803,7 @@ def _random_scene(rt, seed, offset=None):
         return s.material(k, tex0=texs[int(rng.integers(4))], tex1=texs[int(rng.integers(4))], color=tuple(rng.uniform(0.2, 0.9, 3)), p=p)
 
     def wrap(h):
-        for _ in range(int(rng.integers(0, 3))):
+        for _ in range(int(rng.integers(3, 10)) if nesting else int(rng.integers(0, 3))):
             if rng.random() < 0.5:
                 h = s.translate(h, tuple(rng.uniform(-3, 3, 3)))
             else:
@@ -1818,13 +1820,15 @@ def _random_scene(rt, seed, offset=None):
     for _ in range(int(rng.integers(0, 5))):
         mn = rng.uniform(-8, 5, 3)
         wrap(s.gbox(tuple(mn), tuple(mn + rng.uniform(0.5, 4, 3)), material(False)))
-    for _ in range(int(rng.integers(0, 4))):
+    for _ in range(int(rng.integers(33, 48)) if nesting else int(rng.integers(0, 4))):
         if rng.random() < 0.5:
             b = s.sphere(tuple(rng.uniform(-6, 6, 3)), float(rng.uniform(1, 3)), material(True), "boundary")
         else:
             mn = rng.uniform(-7, 3, 3)
             b = s.gbox(tuple(mn), tuple(mn + rng.uniform(1, 5, 3)), material(False))
-        s.constant_medium(wrap(b), float(rng.uniform(0.05, 1.5)), texs[int(rng.integers(3))])
+        m = s.constant_medium(wrap(b), float(rng.uniform(0.05, 1.5)), texs[int(rng.integers(3))])
+        if nesting and rng.random() < 0.5:
+            wrap(m)  # Translate { ptr: ConstantMedium } and RotateY around it: the medium's hit() sees the moved ray
     sky = int(rng.integers(3))
     s.set_sky(sky, "res/newport_loft.jpg" if sky == f.SKY_ENV else None)
     off = np.zeros(3) if offset is None else np.asarray(offset, dtype=np.float64)
@@ -1863,11 +1867,11 @@ def _one_ulp_of_the_direction_moves_it_as_far(orc, renderer, scene, o, d, key, d
 
 
 @pytest.mark.parametrize("seed", list(range(48)))
-def test_random_scenes_bounce_parity(rt, orc, renderer, seed, offset=None):
+def test_random_scenes_bounce_parity(rt, orc, renderer, seed, offset=None, nesting=False):
     """Seeded random scenes over every hitable / material / texture kind: tree search == list walk on the device bit for
     bit, and both == the list-walk oracle (hit, alive, directions exact; t exact except inside media, where ln() differs
     in the last ulp; colours to 2e-5).  `offset` (scripts/gpu_random_scene_sweep.py): scene, camera and rays moved there."""
-    scene = _random_scene(rt, 1000 + seed, offset=offset)
+    scene = _random_scene(rt, 1000 + seed, offset=offset, nesting=nesting)
     renderer.upload(scene)
     rng = np.random.default_rng(seed)
     n = 30000
@@ -1919,6 +1923,22 @@ def test_random_scenes_bounce_parity(rt, orc, renderer, seed, offset=None):
         return  # so far out that every primary direction is the zero vector in fp32: main.rs:39 would panic on each; both sides drop them
     _rays_agree(st, so, scene, p)  # exact per depth unless the scene holds a medium
     _compare_frames(orc, scene, p, img, ref, f"random scene {seed}", rt, renderer)  # no medium, no image: no pixel may be off
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_wrappers_and_media_nest_like_the_trait_objects(rt, orc, renderer, seed):
+    """`Translate`, `RotateY`, `ConstantMedium` and `BvhNode` hold an `Arc<dyn Hitable>` each (hitable.rs:404-588): the reference nests
+    them to any depth and puts any number of media into a world.  Chains of 3-9 wrappers (more than the four the kernels keep in
+    registers: rt_device.h walks those through the list rt_scene_upload builds), 33-47 media (more than the per-lane mask of the
+    closest-hit kernel has bits for, rt_kernels.h media_step; their free-path draws use the counter block above 2^30) and wrappers
+    around media (RtFlatScene::med_xform), per ray through tree and list walk and as frames, against the oracle."""
+    scene = _random_scene(rt, 3000 + seed, nesting=True)
+    a = scene.arrays()
+    depth = np.zeros(scene.flat.n_xforms, np.int64)
+    for x in range(scene.flat.n_xforms):  # a parent precedes its child
+        depth[x] = 1 if a["xf_parent"][x] == rt._ffi.NO_XFORM else depth[a["xf_parent"][x]] + 1
+    assert depth.max() > 4 and scene.flat.n_media > 32 and (a["med_xform"] != rt._ffi.NO_XFORM).any()
+    test_random_scenes_bounce_parity(rt, orc, renderer, 2000 + seed, nesting=True)
 
 
 def test_bench_two_ranks_render_and_gather(tmp_path):
