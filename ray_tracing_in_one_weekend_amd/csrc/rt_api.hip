@@ -1712,7 +1712,7 @@ int rt_debug_arithmetic(RtCtx* ctx, uint32_t op, uint32_t n, const float* x, con
 #ifdef RT_PROFILE_LANES
 // Diagnostic builds only (not declared in include/rtow_mi355x.h, absent from the product library): the lane statistics
 // of rt_kernels.h, optionally reset after reading.
-extern "C" int rt_debug_lane_stats(unsigned long long* out24, int reset) {
+extern "C" int rt_debug_lane_stats(unsigned long long* out24, int reset) { // (RT_LANE_STAT_N values, 48 since round 6)
     if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(rt::g_lane_stats), RT_LANE_STAT_N * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
         const unsigned long long zero[RT_LANE_STAT_N] = {};

@@ -131,8 +131,9 @@ __device__ __forceinline__ int32_t sat_i32(float f) {
 //   depth 0:     12/13 trips of the candidate-list test of k_shade<GEN>   14/15 waves at depth 0 / lanes that have a list
 //   textures:    16/17 waves entering the Perlin turbulence (texture.rs:115-124) / lanes evaluating it
 //   shading:     18/19 64-ray segments shaded by k_shade / lanes holding a ray in them
+//   materials:   20/21 + 2 m: waves / lanes entering the branch of material tag m of shade() (Lambert and the pbr.rs tags: their common part)
 #ifdef RT_PROFILE_LANES
-#define RT_LANE_STAT_N 24
+#define RT_LANE_STAT_N 48
 __device__ unsigned long long g_lane_stats[RT_LANE_STAT_N];
 #define RT_LANE_STAT(I, PRED)                                                                      \
     do {                                                                                           \
@@ -817,9 +818,11 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
 #define RT_TEX0() tex0_value
     switch (m.type) {
     case 0: // Emission material.rs:21-28
+        RT_LANE_STAT(20, true);
         out.radiance = RT_TEX0();
         return out;
     case 1: { // Diffuse material.rs:35-46
+        RT_LANE_STAT(22, true);
         V3 sd = n + normalize(random_in_unit_sphere(rng));
         const float eps = 1.1920929e-7f;
         if (fabsf(sd.x) < eps && fabsf(sd.y) < eps && fabsf(sd.z) < eps) sd = n; // math.rs:8-11
@@ -830,6 +833,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         return out;
     }
     case 3: { // Metal material.rs:66-73
+        RT_LANE_STAT(26, true);
         V3 reflected = reflect(rd, n) + m.p0() * random_in_unit_sphere(rng);
         out.o = p;
         out.d = normalize(reflected);
@@ -838,6 +842,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
         return out;
     }
     case 4: { // Dielectric material.rs:79-97
+        RT_LANE_STAT(28, true);
         float ref_idx = front_face ? 1.0f / m.p0() : m.p0();
         float cos_theta = -fminf(dot(rd, n), 1.0f);
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
@@ -861,6 +866,7 @@ __device__ inline Bounce shade(const DevScene& sc, const PerlinTables& pt, V3 ro
     }
     // Lambert (material.rs:52-59) and the seven pbr.rs materials share: offset origin + a
     // uniform hemisphere direction (pbr.rs:19-20 and equivalents).
+    RT_LANE_STAT(24, true);
     V3 po = offset_hit_point(p, n);
     V3 dir_o = random_on_hemisphere(rng, n);
     out.o = po;

@@ -16,7 +16,8 @@ _ffi.GPU_LIB_PATH = path
 rt.register_default_images()
 names = ["main loop (lanes holding a ray)", "node step", "leaf loop trip", "refill block (lanes refilled)",
          "random_in_unit_sphere: loop trip", "random_in_unit_sphere: call", "depth-0 list test: trip", "depth-0: wave / lanes with a list",
-         "Perlin turbulence: waves entering / lanes", "k_shade: 64-ray segments / lanes with a ray"]
+         "Perlin turbulence: waves entering / lanes", "k_shade: 64-ray segments / lanes with a ray",
+         "shade(): Emission", "shade(): Diffuse", "shade(): Lambert + pbr.rs", "shade(): Metal", "shade(): Dielectric"]
 for name in scenes:
     scene = rt.Scene.build(name, 16 / 9)
     r = rt.Renderer(0)
@@ -24,7 +25,7 @@ for name in scenes:
     lib = _ffi.load_gpu_library()
     fn = lib.rt_debug_lane_stats
     fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
-    out = (ctypes.c_ulonglong * 24)()
+    out = (ctypes.c_ulonglong * 48)()
     p = rt.make_params(1920, 1080, spp, max_depth=50)
     assert fn(out, 1) == 0
     _, _, st = r.render(scene.camera, p)

@@ -36,7 +36,8 @@ for seed in range(first, first + n):
         off = orng.normal(size=3) * 10.0 ** orng.uniform(3.0, far_exp)
         n_far += 1
     fn(rt, orc, r, seed, offset=off, nesting=nesting)
-    s = T._random_scene(rt, 1000 + seed, nesting=nesting).flat
+    scene = T._random_scene(rt, 1000 + seed, nesting=nesting)  # (kept alive: .flat points into it)
+    s = scene.flat
     print(f"seed {seed}: ok  " + ("" if off is None else f"[moved {np.abs(off).max():.1e} out] ") + f"({s.n_spheres} spheres, {s.n_rects} rectangles, {s.n_xforms} wrappers, {s.n_media} media, sky {s.sky_type})  {time.time() - t0:6.1f} s", flush=True)
 print(f"{n} scenes{' with deep nesting' if nesting else ''}, seeds {first}..{first + n - 1} ({n_far} of them moved up to 1e{far_exp:g} units out): all per-ray records and frames agree with the oracle")
 r.close()
