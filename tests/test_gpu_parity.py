@@ -806,6 +806,35 @@ def test_error_behaviour(rt):
     r.close()
 
 
+def test_a_wrapper_around_a_medium_must_lie_on_its_boundary_chains(rt):
+    """RtFlatScene::med_xform names the innermost wrapper AROUND a medium; the chains of the boundary's primitives run through it.
+    A wrapper index beyond the table, or one that no boundary chain passes, is RT_ERR_INVALID — and a NULL med_xform (a host written
+    against ABI 10's meaning: no wrappers around media) still uploads."""
+    import ctypes as C
+    f = rt._ffi
+    s = rt.Scene.new()
+    fog = s.constant_tex((0.5, 0.5, 0.5))
+    m = s.constant_medium(s.translate(s.sphere((0, 0, 0), 1.0, s.material(f.MAT_DIELECTRIC, p=(1.5,)), "b"), (1, 0, 0)), 0.5, fog)
+    s.rotate_y(m, 30.0)                                     # chain of the boundary sphere: Translate (inside) -> RotateY (around)
+    other = s.translate(s.sphere((5, 0, 0), 1.0, s.material(f.MAT_DIELECTRIC, p=(1.5,)), "o"), (0, 1, 0))
+    s.set_camera((0, 0, 10), (0, 0, 0), (0, 1, 0), 30, 1.0)
+    scene = s.finish()
+    a = scene.arrays()
+    assert scene.flat.n_xforms == 3 and a["med_xform"].tolist() == [0] and a["xf_parent"].tolist()[1] == 0  # RotateY was opened first
+    r = rt.Renderer(0)
+    r.upload(scene)
+    for bad, what in ((7, "bad wrapper"), (int(a["sph_xform"][1]), "not on the chain")):
+        fs = rt.RtFlatScene.from_buffer_copy(scene.flat)
+        arr = (C.c_uint32 * 1)(bad)
+        fs.med_xform = C.cast(arr, C.POINTER(C.c_uint32))
+        with pytest.raises(rt.RtError, match=what):
+            r.upload(fs)
+    fs = rt.RtFlatScene.from_buffer_copy(scene.flat)
+    fs.med_xform = C.POINTER(C.c_uint32)()
+    r.upload(fs)
+    r.close()
+
+
 def test_non_finite_geometry_is_rejected(rt):
     """A NaN / infinite centre, radius, rectangle bound or transform parameter would reach the tree builder's sort
     comparators (host-side undefined behaviour): rt_scene_upload returns RT_ERR_INVALID instead."""
