@@ -84,6 +84,9 @@ typedef struct RtSceneInfo {
     uint32_t grid_always;          /* large spheres tested for every ray */
     uint32_t grid_lds_bytes;
     float grid_cell_size[3];
+    uint32_t general_tables_in_lds; /* 1: the wrapper / medium tables of a general scene are staged in LDS beside the tree or its stacks */
+    uint32_t nest;                  /* 1: the scene nests beyond what the kernels keep in registers (a wrapper chain of more than 4, more
+                                     * than 32 media, a wrapper around a medium): the instantiations with the loops run (csrc/rt_device.h) */
 } RtSceneInfo;
 int rt_debug_scene_info(const RtCtx* ctx, RtSceneInfo* info);
 

@@ -111,7 +111,7 @@ class RtSceneInfo(C.Structure):
     _fields_ = [("n_entries", C.c_uint32), ("n_tree_nodes", C.c_uint32), ("tree_depth", C.c_uint32), ("tree_in_lds", C.c_uint32),
                 ("general_kernels", C.c_uint32), ("closest_hit_lds_bytes", C.c_uint32), ("grid", C.c_uint32),
                 ("grid_cells", C.c_uint32 * 3), ("grid_refs", C.c_uint32), ("grid_always", C.c_uint32),
-                ("grid_lds_bytes", C.c_uint32), ("grid_cell_size", C.c_float * 3)]
+                ("grid_lds_bytes", C.c_uint32), ("grid_cell_size", C.c_float * 3), ("general_tables_in_lds", C.c_uint32), ("nest", C.c_uint32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("grid_cells", "grid_cell_size")}

@@ -784,11 +784,18 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     // chains through the parent links into registers and long ones through the list).
     uint32_t n_xf_listed = 0;
     std::vector<uint32_t> xf_depth(s->n_xforms);
+    std::vector<uint8_t> xf_is_innermost(s->n_xforms, 0); // only the wrapper a primitive or a medium names is ever looked up by a kernel
+    for (uint32_t i = 0; i < s->n_spheres && s->sph_xform; ++i)
+        if (s->sph_xform[i] != RT_NO_XFORM) xf_is_innermost[s->sph_xform[i]] = 1;
+    for (uint32_t i = 0; i < s->n_rects && s->rect_xform; ++i)
+        if (s->rect_xform[i] != RT_NO_XFORM) xf_is_innermost[s->rect_xform[i]] = 1;
+    for (uint32_t m = 0; m < s->n_media && s->med_xform; ++m)
+        if (s->med_xform[m] != RT_NO_XFORM && s->med_xform[m] < s->n_xforms) xf_is_innermost[s->med_xform[m]] = 1;
     for (uint32_t i = 0; i < s->n_xforms; ++i) {
         const uint32_t depth = xf_depth[i] = s->xf_parent[i] == RT_NO_XFORM ? 1u : xf_depth[s->xf_parent[i]] + 1u;
         xparam[i] = make_float4(s->xf_param[4 * i], s->xf_param[4 * i + 1], s->xf_param[4 * i + 2], 0.0f);
         xmeta[i] = make_uint2(s->xf_type[i], s->xf_parent[i]);
-        if (depth > (uint32_t)RT_MAX_CHAIN) {
+        if (depth > (uint32_t)RT_MAX_CHAIN && xf_is_innermost[i]) {
             if ((uint64_t)s->n_xforms + n_xf_listed + depth > 0x7FFFFFFFull) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_scene_upload: wrapper chains too long to list");
             xparam[i].w = fbits(s->n_xforms + n_xf_listed);
             n_xf_listed += depth;
@@ -796,7 +803,7 @@ int rt_scene_upload(RtCtx* ctx, const RtFlatScene* s) {
     }
     xmeta.resize((size_t)s->n_xforms + n_xf_listed);
     for (uint32_t i = 0; i < s->n_xforms; ++i) {
-        if (xf_depth[i] <= (uint32_t)RT_MAX_CHAIN) continue;
+        if (xf_depth[i] <= (uint32_t)RT_MAX_CHAIN || !xf_is_innermost[i]) continue;
         uint32_t p0, k = xf_depth[i];
         std::memcpy(&p0, &xparam[i].w, 4);
         for (uint32_t x = i; x != RT_NO_XFORM; x = s->xf_parent[x]) xmeta[p0 + --k] = make_uint2(x, xf_depth[i]);
@@ -1509,6 +1516,8 @@ int rt_debug_scene_info(const RtCtx* ctx, RtSceneInfo* info) {
     info->general_kernels = scene_is_general(ctx);
     info->closest_hit_lds_bytes = (uint32_t)ctx->isect_lds;
     info->grid = ctx->use_grid;
+    info->general_tables_in_lds = ctx->general_lds;
+    info->nest = ctx->nest;
     if (ctx->use_grid) {
         info->grid_cells[0] = ctx->grid.nx, info->grid_cells[1] = ctx->grid.ny, info->grid_cells[2] = ctx->grid.nz;
         info->grid_refs = ctx->grid.all_rec >> RT_GRID_CNT_BITS;

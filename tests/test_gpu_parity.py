@@ -1970,6 +1970,87 @@ def test_wrappers_and_media_nest_like_the_trait_objects(rt, orc, renderer, seed)
     test_random_scenes_bounce_parity(rt, orc, renderer, 2000 + seed, nesting=True)
 
 
+def _nested_cloud(rt, n_spheres, shared_chain, own_chains, n_media):
+    """An instanced cloud like final_scene's (demo_scene.rs:176-182) taken further: `n_spheres` small spheres below a SHARED chain of
+    `shared_chain` wrappers each, equal from sphere to sphere (0: a bare cloud), `own_chains` spheres below 5-7 wrappers of their own,
+    plus `n_media` fog boxes, every other one with three wrappers around the medium."""
+    rng = np.random.default_rng(123)
+    f = rt._ffi
+    s = rt.Scene.new()
+    white = s.material(f.MAT_DIFFUSE, tex0=s.constant_tex((0.73, 0.73, 0.73)))
+    metal = s.material(f.MAT_METAL, color=(0.8, 0.8, 0.9), p=(0.3,))
+    s.sphere((0.0, -1000.0, 0.0), 1000.0, s.material(f.MAT_LAMBERT, tex0=s.checker_tex((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))), "ground")
+    s.rect(f.RECT_XZ, (-40.0, 120.0, -40.0), (40.0, 120.0, 40.0), s.material(f.MAT_EMISSION, tex0=s.constant_tex((7, 7, 7))))
+
+    def chain(h, n):
+        for _ in range(n):
+            h = s.translate(h, tuple(rng.uniform(-4, 4, 3))) if rng.random() < 0.5 else s.rotate_y(h, float(rng.uniform(-40, 40)))
+        return h
+
+    first = None
+    for k in range(n_spheres - own_chains):  # the cloud (rth_* wrap one handle at a time: the chain is built per sphere from the same draws)
+        h = s.sphere(tuple(rng.uniform(0, 100, 3) + (0, 5, 0)), 2.0, white if k % 3 else metal, "cloud")
+        first = h if first is None else first
+    state = rng.bit_generator.state
+    for h in range(first, first + n_spheres - own_chains):
+        rng.bit_generator.state = state
+        chain(h, shared_chain)
+    for _ in range(own_chains):
+        chain(s.sphere(tuple(rng.uniform(-60, 60, 3) * (1, 0.3, 1) + (0, 25, 0)), 3.0, metal, "own"), int(rng.integers(5, 8)))
+    fog = s.constant_tex((0.6, 0.7, 0.9))
+    for m in range(n_media):
+        mn = rng.uniform(-70, 50, 3) * (1, 0, 1) + (0, 1, 0)
+        h = s.constant_medium(chain(s.gbox(tuple(mn), tuple(mn + rng.uniform(8, 20, 3)), white), 2), 0.05, fog)
+        if m % 2:
+            chain(h, 3)
+    s.set_sky(f.SKY_BLACK)
+    s.set_camera((160, 60, -160), (20, 30, 20), (0, 1, 0), 40, 1.5)
+    return s.finish()
+
+
+@pytest.mark.parametrize("n_spheres,shared_chain,own_chains,lds_tree,lds_tables", [(2400, 6, 0, False, False), (2400, 0, 40, False, True),
+                                                                                    (150, 0, 30, True, True), (150, 7, 20, True, False)])
+def test_nested_scenes_through_every_placement_of_tree_and_tables(rt, orc, renderer, n_spheres, shared_chain, own_chains, lds_tree, lds_tables):
+    """The NEST instantiations of the closest-hit kernel (rt_device.h) with the tree in LDS and read through L2, with the wrapper /
+    medium tables staged in LDS and read from memory: final_scene-sized instanced clouds below chains of 6-7 wrappers, 36 media, half
+    of them below wrappers of their own.  Per ray (the single-kernel hook AND the production kernels through the queue) and as a
+    frame against the oracle; tree == list walk on the device."""
+    scene = _nested_cloud(rt, n_spheres, shared_chain, own_chains, 36)
+    renderer.upload(scene)
+    info = renderer.scene_info()
+    assert info["nest"] == 1 and info["general_kernels"] == 1
+    assert (info["tree_in_lds"], info["general_tables_in_lds"]) == (int(lds_tree), int(lds_tables)), info
+    rng = np.random.default_rng(n_spheres + own_chains)
+    n = 20000
+    o = (rng.uniform(-90, 130, size=(n, 3)) * (1, 0.5, 1) + (0, 2, 0)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    ln = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]).astype(np.float32)
+    d = (d * (np.float32(1) / ln)[:, None]).astype(np.float32)
+    keys = path_keys(0, np.arange(n), np.zeros(n, dtype=np.uint64))  # what the production kernels derive from the slot
+    g = renderer.debug_bounce(o, d, keys, depth=2)
+    b = renderer.debug_bounce(o, d, keys, depth=2, flags=rt._ffi.FLAG_BRUTE_FORCE)
+    p = renderer.debug_bounce(o, d, keys, depth=2, flags=rt._ffi.FLAG_PRODUCTION_KERNELS)
+    c = orc.debug_bounce(scene.flat_ptr, o, d, keys, depth=2, accel=orc.ACCEL_LIST)
+    for k in g:
+        assert np.array_equal(g[k].view(np.uint8), b[k].view(np.uint8)), k
+    n_prims = scene.flat.n_spheres + scene.flat.n_rects
+    med = c["hit"] >= n_prims
+    assert (c["hit"] >= 0).mean() > 0.5 and med.mean() > 0.01
+    for dev in (g, p):
+        assert np.array_equal(dev["hit"], c["hit"]) and np.array_equal(dev["alive"], c["alive"])
+        assert np.array_equal(dev["t"][~med].view(np.uint32), c["t"][~med].view(np.uint32)) and np.allclose(dev["t"][med], c["t"][med], rtol=4e-6)
+        live = c["alive"].astype(bool)
+        assert np.array_equal(dev["d"][live].view(np.uint32), c["d"][live].view(np.uint32))
+        assert np.array_equal(dev["o"][live & ~med].view(np.uint32), c["o"][live & ~med].view(np.uint32))
+        assert np.allclose(dev["o"][live & med], c["o"][live & med], rtol=1e-5, atol=1e-3)
+        assert np.allclose(dev["attenuation"][live], c["attenuation"][live], rtol=2e-5, atol=1e-6)
+    prm = rt.make_params(96, 64, 4, max_depth=8)
+    img, _, st = renderer.render(scene.camera, prm)
+    ref, _, so = _oracle(orc, scene, prm, accel=orc.ACCEL_LIST)
+    _rays_agree(st, so, scene, prm)
+    _compare_frames(orc, scene, prm, img, ref, f"nested cloud {n_spheres} / {own_chains}", rt, renderer)
+
+
 def test_bench_two_ranks_render_and_gather(tmp_path):
     """`python bench.py --gpus 2` end to end on this one GPU: the ranks start themselves, both render their interleaved bands of
     the frame on device 0 (RTOW_DIST_BACKEND=gloo: the gather goes through host memory — the rehearsal of the RCCL run that no
