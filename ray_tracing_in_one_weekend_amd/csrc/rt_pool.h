@@ -20,7 +20,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
