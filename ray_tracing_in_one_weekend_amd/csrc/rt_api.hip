@@ -281,7 +281,8 @@ bool scene_perlin_lds(const RtCtx* ctx) { return ctx->ds.n_perlin > 0 && ctx->ds
 void launch_intersect(RtCtx* ctx, hipStream_t sg, bool use_bvh, bool gen, uint32_t grid, const StepBuffers& b, const IntersectParams& ip) {
     const bool rects = scene_is_general(ctx);
     if (use_bvh && !gen && grid_enabled(ctx)) { // sphere-only scene, depth >= 1: the grid walk (rt_grid.h), same hit records
-        hipLaunchKernelGGL(k_intersect_grid, dim3(grid), dim3(RT_BVH_BLOCK), ctx->grid_lds, sg, ctx->grid, b.qi.a, b.qi.b, b.qhit, b.cin, ip);
+        if (ctx->grid.ny == 1u) hipLaunchKernelGGL(k_intersect_grid<true>, dim3(grid), dim3(RT_BVH_BLOCK), ctx->grid_lds, sg, ctx->grid, b.qi.a, b.qi.b, b.qhit, b.cin, ip);
+        else hipLaunchKernelGGL(k_intersect_grid<false>, dim3(grid), dim3(RT_BVH_BLOCK), ctx->grid_lds, sg, ctx->grid, b.qi.a, b.qi.b, b.qhit, b.cin, ip);
         return;
     }
 #define RT_LAUNCH_ISECT_X(G, R, N, T, X)                                                                               \
@@ -514,7 +515,7 @@ int rt_ctx_create(int device_id, RtCtx** out_ctx) {
             RT_ISECT_VARIANTS(false, true, false), RT_ISECT_VARIANTS(true, true, false), RT_ISECT_VARIANTS(false, false, false), RT_ISECT_VARIANTS(true, false, false),
             RT_ISECT_VARIANTS(false, true, true),  RT_ISECT_VARIANTS(true, true, true),  RT_ISECT_VARIANTS(false, false, true),  RT_ISECT_VARIANTS(true, false, true),
 #undef RT_ISECT_VARIANTS
-            reinterpret_cast<const void*>(&k_intersect_grid),
+            reinterpret_cast<const void*>(&k_intersect_grid<true>), reinterpret_cast<const void*>(&k_intersect_grid<false>),
             reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, true>),
             reinterpret_cast<const void*>(&k_debug_bounce<RT_BVH_BLOCK, true, false>),
 #define RT_SHADE_VARIANTS(P, G) reinterpret_cast<const void*>(&k_shade<P, G, false>), reinterpret_cast<const void*>(&k_shade<P, G, true>), reinterpret_cast<const void*>(&k_shade<P, G, true, true>)

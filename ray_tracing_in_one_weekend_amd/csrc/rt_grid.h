@@ -231,6 +231,11 @@ inline void build_sphere_grid(const std::vector<float4>& sph, size_t lds_budget,
 // The large spheres are tested when a lane takes its ray, all refilled lanes together.  (One loop over the candidates left
 // by a cheap pre-pass — behind the origin, negative discriminant — so that the square root and the divisions run once per
 // trip instead of once per large sphere: 3 % slower, the pre-pass repeats 20 instructions per sphere.)
+// ONE_LAYER (ny == 1, the usual case: sphere_scene's 0.4-high layer of small spheres is 41 x 1 x 42 cells): the walk never steps in y —
+// the plane through which the ray leaves its cell in y is the one through which it leaves the grid, and `texit` already ends the walk
+// there — so the y terms of the DDA (six instructions of the set-up, five of every step, three registers) are left out.  Whether the
+// general form took that last step (an ulp decides between its tmy and texit) or not, it only ever added redundant tests.
+template <bool ONE_LAYER>
 __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G, const float4* __restrict__ qa,
                                                                       const float4* __restrict__ qb, float2* __restrict__ qh,
                                                                       const uint32_t* __restrict__ in_counts, IntersectParams ip) {
@@ -333,16 +338,16 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
                 } else {
                     const float px = __builtin_fmaf(d.x, tn, o.x), py = __builtin_fmaf(d.y, tn, o.y), pz = __builtin_fmaf(d.z, tn, o.z);
                     const float fx = fminf(fmaxf(floorf((px - G.g0[0]) * G.inv_cs[0]), 0.0f), (float)(G.nx - 1u));
-                    const float fy = fminf(fmaxf(floorf((py - G.g0[1]) * G.inv_cs[1]), 0.0f), (float)(G.ny - 1u));
+                    const float fy = ONE_LAYER ? 0.0f : fminf(fmaxf(floorf((py - G.g0[1]) * G.inv_cs[1]), 0.0f), (float)(G.ny - 1u));
                     const float fz = fminf(fmaxf(floorf((pz - G.g0[2]) * G.inv_cs[2]), 0.0f), (float)(G.nz - 1u));
-                    cell = ((int)fz * (int)G.ny + (int)fy) * (int)G.nx + (int)fx;
+                    cell = ONE_LAYER ? (int)fz * (int)G.nx + (int)fx : ((int)fz * (int)G.ny + (int)fy) * (int)G.nx + (int)fx;
                     // a component too small to ever reach the next plane (1/d infinite, NaN or beyond 1e30): never stepped
                     const bool wx = fabsf(ix) < 1e30f, wy = fabsf(iy) < 1e30f, wz = fabsf(iz) < 1e30f;
                     const float bx = __builtin_fmaf(fx + (d.x >= 0.0f ? 1.0f : 0.0f), G.cs[0], G.g0[0]);
                     const float by = __builtin_fmaf(fy + (d.y >= 0.0f ? 1.0f : 0.0f), G.cs[1], G.g0[1]);
                     const float bz = __builtin_fmaf(fz + (d.z >= 0.0f ? 1.0f : 0.0f), G.cs[2], G.g0[2]);
                     tmx = wx ? (bx - o.x) * ix : INFINITY, tdx = wx ? G.cs[0] * fabsf(ix) : INFINITY;
-                    tmy = wy ? (by - o.y) * iy : INFINITY, tdy = wy ? G.cs[1] * fabsf(iy) : INFINITY;
+                    if (!ONE_LAYER) tmy = wy ? (by - o.y) * iy : INFINITY, tdy = wy ? G.cs[1] * fabsf(iy) : INFINITY;
                     tmz = wz ? (bz - o.z) * iz : INFINITY, tdz = wz ? G.cs[2] * fabsf(iz) : INFINITY;
                     sx = d.x >= 0.0f ? 1 : -1, sy = d.y >= 0.0f ? stride_y : -stride_y, sz = d.z >= 0.0f ? stride_z : -stride_z;
                     texit = tf;
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
         // ---- walk: a lane whose cell is used up steps to the next cell, or finishes
         RT_LANE_STAT(2, has && cnt == 0u);
         if (has && cnt == 0u) {
-            const float tnext = fminf(fminf(tmx, tmy), tmz);
+            const float tnext = ONE_LAYER ? fminf(tmx, tmz) : fminf(fminf(tmx, tmy), tmz);
             if (!(tnext < fminf(tbest, texit))) { // the best root lies inside the cells visited, or the ray has left the grid
                 qh[pos] = make_float2(tbest, __int_as_float(hit));
                 has = false;
@@ -368,10 +373,10 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
                 texit = -RT_FLT_MAX;
                 tmx = tmy = tmz = INFINITY; // tnext = inf is never < min(tbest, texit): the lane finishes right behind the list
             } else {
-                const bool ax = tmx <= tnext, ay = !ax && tmy <= tnext, az = !ax && !ay;
+                const bool ax = tmx <= tnext, ay = !ONE_LAYER && !ax && tmy <= tnext, az = !ax && !ay;
                 cell += ax ? sx : (ay ? sy : sz);
                 tmx = ax ? tmx + tdx : tmx;
-                tmy = ay ? tmy + tdy : tmy;
+                if (!ONE_LAYER) tmy = ay ? tmy + tdy : tmy;
                 tmz = az ? tmz + tdz : tmz;
                 const uint32_t rec = s_cells[min((uint32_t)cell, last_cell)];
                 cnt = rec & RT_GRID_CNT_MASK, off = rec >> RT_GRID_CNT_BITS;
