@@ -235,6 +235,11 @@ inline void build_sphere_grid(const std::vector<float4>& sph, size_t lds_budget,
 // the plane through which the ray leaves its cell in y is the one through which it leaves the grid, and `texit` already ends the walk
 // there — so the y terms of the DDA (six instructions of the set-up, five of every step, three registers) are left out.  Whether the
 // general form took that last step (an ulp decides between its tmy and texit) or not, it only ever added redundant tests.
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 template <bool ONE_LAYER>
 __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G, const float4* __restrict__ qa,
                                                                       const float4* __restrict__ qb, float2* __restrict__ qh,
@@ -269,6 +274,7 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
     const uint32_t lane = threadIdx.x & 63u;
     const int stride_y = (int)G.nx, stride_z = (int)(G.nx * G.ny);
     const uint32_t last_cell = G.n_cells - 1u;
+    const uint32_t all_cnt = G.all_rec & RT_GRID_CNT_MASK, all_off = G.all_rec >> RT_GRID_CNT_BITS; // the list of every sphere
     bool exhausted = false; // wave-uniform: the workgroup has no unclaimed rays left
     bool has = false;
     V3 o = splat(0.0f), d = v3(0.f, 0.f, 1.f);
@@ -285,6 +291,13 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
             hit = (int)s;
         }
     };
+    // (the shard the wave's claims are in: see the refill)
+    uint32_t cur_k = 0u, cur_lo = 0u, cur_hi = pre[1];
+    size_t cur_base = (size_t)(ip.q0 + blockIdx.x) * ip.cap;
+    auto q_finish = [&]() {
+        qh[pos] = make_float2(tbest, __int_as_float(hit));
+        has = false;
+    };
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -297,19 +310,42 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
             if (v0 + n_idle >= total) exhausted = true;
             const uint32_t v =
                 v0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            // The shard of a claimed ray.  A workgroup's claims only move forward through its virtual index space, and the rays of one
+            // claim are consecutive: the wave keeps the shard its last claim started in (`cur_k`, the part [cur_lo, cur_hi) of the index
+            // space, the queue position `cur_base` of index 0 of that part — all scalar), advances it when a claim starts beyond it, and
+            // every lane of a claim that ends inside it gets its position by ONE 64-bit addition.  Only a claim that straddles a shard
+            // boundary (at most three per workgroup and wave) searches per lane — which every refill used to do: 20 of its ~175
+            // vector instructions.
+            while (v0 >= cur_hi && cur_k + 1u < n_my) { // (wave-uniform)
+                ++cur_k;
+                cur_lo = cur_hi;
+                uint32_t nh = total;
+#pragma unroll
+                for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) nh = (cur_k + 1u == t) ? pre[t] : nh;
+                cur_hi = nh;
+                cur_base = (size_t)(ip.q0 + blockIdx.x + cur_k * gridDim.x) * ip.cap - cur_lo;
+            }
             if (!has && v < total) {
-                uint32_t k = 0;
-#pragma unroll
-                for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) k += (t < n_my && v >= pre[t]) ? 1u : 0u;
-                uint32_t qoff = v;
-#pragma unroll
-                for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) qoff = (k == t) ? v - pre[t] : qoff;
-                const uint32_t shard = ip.q0 + blockIdx.x + k * gridDim.x;
-                pos = (size_t)shard * ip.cap + qoff;
+                if (min(v0 + n_idle, total) <= cur_hi) { // (wave-uniform) the whole claim lies in the current shard
+                    pos = cur_base + v;
 #ifdef RT_DEBUG_QUEUE_BOUNDS
-                if (qoff >= ip.cap || shard >= ip.q1) __builtin_trap();
+                    if (v - cur_lo >= ip.cap || ip.q0 + blockIdx.x + cur_k * gridDim.x >= ip.q1) __builtin_trap();
 #endif
-                const float4 ra = qa[RT_QSTRIDE * pos], rb = qb[RT_QSTRIDE * pos];
+                } else {
+                    uint32_t k = 0;
+#pragma unroll
+                    for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) k += (t < n_my && v >= pre[t]) ? 1u : 0u;
+                    uint32_t qoff = v;
+#pragma unroll
+                    for (uint32_t t = 1; t < RT_ISECT_MAX_SHARDS; ++t) qoff = (k == t) ? v - pre[t] : qoff;
+                    const uint32_t shard = ip.q0 + blockIdx.x + k * gridDim.x;
+                    pos = (size_t)shard * ip.cap + qoff;
+#ifdef RT_DEBUG_QUEUE_BOUNDS
+                    if (qoff >= ip.cap || shard >= ip.q1) __builtin_trap();
+#endif
+                }
+                // (with the two halves of a ray's record interleaved, b = a + 1: one address)
+                const float4 ra = qa[RT_QSTRIDE * pos], rb = RT_QSTRIDE == 2u ? qa[RT_QSTRIDE * pos + 1u] : qb[RT_QSTRIDE * pos];
                 o = v3(ra.x, ra.y, ra.z);
                 d = v3(rb.x, rb.y, rb.z);
                 rcp_a = shared_rcp(length_squared(d));
@@ -328,18 +364,18 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
                 const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
                 const float mo = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
                 cnt = 0u;
-                if (!(mo <= G.max_coord)) { // far away (or NaN): every sphere, no walk
-                    cnt = G.all_rec & RT_GRID_CNT_MASK, off = G.all_rec >> RT_GRID_CNT_BITS;
-                    texit = -RT_FLT_MAX;
-                    tmx = tmy = tmz = INFINITY; // (the walk step behind the list then finishes the ray whatever tbest holds)
+                if (__builtin_expect(!(mo <= G.max_coord), 0)) { // far away (or NaN): every sphere, here and now, no walk (a cold block
+                    // of its own, like the step budget below: as a state of the walk it cost every refill six constants and eight copies)
+                    for (uint32_t k = 0; k < all_cnt; ++k) test_sphere(s_refs[all_off + k]);
+                    q_finish();
                 } else if (!(tn <= tf) || !(tn < tbest)) { // misses the grid, or reaches it behind the best large sphere
                     qh[pos] = make_float2(tbest, __int_as_float(hit));
                     has = false;
                 } else {
                     const float px = __builtin_fmaf(d.x, tn, o.x), py = __builtin_fmaf(d.y, tn, o.y), pz = __builtin_fmaf(d.z, tn, o.z);
-                    const float fx = fminf(fmaxf(floorf((px - G.g0[0]) * G.inv_cs[0]), 0.0f), (float)(G.nx - 1u));
-                    const float fy = ONE_LAYER ? 0.0f : fminf(fmaxf(floorf((py - G.g0[1]) * G.inv_cs[1]), 0.0f), (float)(G.ny - 1u));
-                    const float fz = fminf(fmaxf(floorf((pz - G.g0[2]) * G.inv_cs[2]), 0.0f), (float)(G.nz - 1u));
+                    const float fx = min_raw(fmaxf(floorf((px - G.g0[0]) * G.inv_cs[0]), 0.0f), (float)(G.nx - 1u));
+                    const float fy = ONE_LAYER ? 0.0f : min_raw(fmaxf(floorf((py - G.g0[1]) * G.inv_cs[1]), 0.0f), (float)(G.ny - 1u));
+                    const float fz = min_raw(fmaxf(floorf((pz - G.g0[2]) * G.inv_cs[2]), 0.0f), (float)(G.nz - 1u));
                     cell = ONE_LAYER ? (int)fz * (int)G.nx + (int)fx : ((int)fz * (int)G.ny + (int)fy) * (int)G.nx + (int)fx;
                     // a component too small to ever reach the next plane (1/d infinite, NaN or beyond 1e30): never stepped
                     const bool wx = fabsf(ix) < 1e30f, wy = fabsf(iy) < 1e30f, wz = fabsf(iz) < 1e30f;
@@ -364,14 +400,12 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
         // ---- walk: a lane whose cell is used up steps to the next cell, or finishes
         RT_LANE_STAT(2, has && cnt == 0u);
         if (has && cnt == 0u) {
-            const float tnext = ONE_LAYER ? fminf(tmx, tmz) : fminf(fminf(tmx, tmy), tmz);
-            if (!(tnext < fminf(tbest, texit))) { // the best root lies inside the cells visited, or the ray has left the grid
+            // (v_min_f32 itself: fminf() of two loop-carried values costs a canonicalising v_max x, x per operand in front of it, four
+            // of the step's ~25 instructions; none of these is ever a NaN — distances, INFINITY, FLT_MAX)
+            const float tnext = ONE_LAYER ? min_raw(tmx, tmz) : min_raw(min_raw(tmx, tmy), tmz);
+            if (!(tnext < min_raw(tbest, texit))) { // the best root lies inside the cells visited, or the ray has left the grid
                 qh[pos] = make_float2(tbest, __int_as_float(hit));
                 has = false;
-            } else if (--budget == 0u) { // cannot happen for a DDA; keeps the loop finite whatever the arithmetic did
-                cnt = G.all_rec & RT_GRID_CNT_MASK, off = G.all_rec >> RT_GRID_CNT_BITS;
-                texit = -RT_FLT_MAX;
-                tmx = tmy = tmz = INFINITY; // tnext = inf is never < min(tbest, texit): the lane finishes right behind the list
             } else {
                 const bool ax = tmx <= tnext, ay = !ONE_LAYER && !ax && tmy <= tnext, az = !ax && !ay;
                 cell += ax ? sx : (ay ? sy : sz);
@@ -380,6 +414,14 @@ __global__ __launch_bounds__(RT_BVH_BLOCK, 8) void k_intersect_grid(GridParams G
                 tmz = az ? tmz + tdz : tmz;
                 const uint32_t rec = s_cells[min((uint32_t)cell, last_cell)];
                 cnt = rec & RT_GRID_CNT_MASK, off = rec >> RT_GRID_CNT_BITS;
+                // cannot happen for a DDA; keeps the loop finite whatever the arithmetic did: every sphere, here and now.  (As a state
+                // of the walk — the list of all spheres as the lane's cell, infinite plane distances — its five constants were set up
+                // on every trip of every lane.)
+                if (__builtin_expect(--budget == 0u, 0)) {
+                    for (uint32_t k = 0; k < all_cnt; ++k) test_sphere(s_refs[all_off + k]);
+                    q_finish();
+                    cnt = 0u;
+                }
             }
         }
         // ---- test: one sphere per lane that has one
