@@ -17,7 +17,7 @@ b2 = json.load(open(P + "bench_config2.json"))
 t2 = json.load(open(P + "traffic_config2.json")) if os.path.exists(P + "traffic_config2.json") else None
 v2 = json.load(open(P + "valu_config2.json"))["kernels"] if os.path.exists(P + "valu_config2.json") else None
 cb = b2["cpu_baseline"]
-block = (f"| round 6: the grid walk of a single-layer grid without the y terms of its DDA (-1.4 % of the frame; the other experiments on the kernels filed, section 9); all device memory of a context in one range grown by a helper thread; wrappers and media nest without limit.  Leases of this round before the grid change: 43.92 / 44.03 / 44.04 / 44.33 / 45.50 / 46.03 ms per frame — boxes differ by that much; the committed line is the last one taken | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
+block = (f"| round 6: the grid walk read in its ISA (single-layer form, raw `v_min`, the cannot-happen exits as cold blocks, the shard of a claim as scalar state: `k_intersect_grid` -9 %, the frame -3 % on one box; the other experiments on the kernels filed, section 9); all device memory of a context in one range grown by a helper thread; wrappers and media nest without limit.  Leases of this round: 43.92 / 44.03 / 44.04 / 44.33 / 45.50 / 46.03 ms per frame before the grid work, 43.40 with the single-layer form, 43.51 with all of it — boxes differ by more than the change; the committed line is the last one taken, the A/Bs on one box are in `profiles/round6/ab_grid_walk_*` | **{sp(b2['value'])}** | **{b2['ms_per_step']:.2f}** | "
          f"{100 * b2['roofline']['frac']:.1f} % |\n"
          f"| CPU oracle, stream order + BVH, {cb['cores']} host cores (EPYC 9575F), the faster of the portable and the `-march=native` build | "
          f"{cb['value']:.1f} | — | — |\n\n"
