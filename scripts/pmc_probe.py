@@ -57,7 +57,7 @@ for g, ctrs in GROUPS.items():
     data[g] = [(name, us, vals.get(did, {})) for did, name, us in disp]
 
 n = min(len(v) for v in data.values())
-print("%-3s %-34s %9s %9s %9s %7s | %6s %6s %6s %6s %6s | %7s %9s" % ("#", "kernel", "us", "fetchMB", "writeMB", "TB/s", "wait", "winst", "valu", "lane", "ldscf", "icmiss", "icreq/us"))
+print("%-3s %-34s %9s %9s %9s %7s | %6s %6s %6s %6s %6s %6s | %7s %9s" % ("#", "kernel", "us", "fetchMB", "writeMB", "TB/s", "wait", "winst", "valu", "lane", "lds", "ldscf", "icmiss", "icreq/us"))
 tot = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0])
 for i in range(n):
     name, us, _ = data["fetch"][i]
@@ -70,10 +70,10 @@ for i in range(n):
     t = tot[name]
     t[0] += us; t[1] += f; t[2] += w; t[3] += 1
     if i < 40:
-        print("%-3d %-34s %9.1f %9.1f %9.1f %7.2f | %6.2f %6.2f %6.2f %6.2f %6.2f | %7.4f %9.0f" % (
+        print("%-3d %-34s %9.1f %9.1f %9.1f %7.2f | %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f | %7.4f %9.0f" % (
             i, name[:34], us, f / 1e6, w / 1e6, (f + w) / us / 1e6, sq.get("SQ_WAIT_ANY", 0) / wc, sq.get("SQ_WAIT_INST_ANY", 0) / wc,
             sq.get("SQ_ACTIVE_INST_VALU", 0) / wc, sq.get("SQ_THREAD_CYCLES_VALU", 0) / max(64 * sq.get("SQ_ACTIVE_INST_VALU", 0), 1),
-            ld.get("SQ_LDS_BANK_CONFLICT", 0) / max(ld.get("SQ_LDS_IDX_ACTIVE", 0), 1),
+            sq.get("SQ_ACTIVE_INST_LDS", 0) / wc, ld.get("SQ_LDS_BANK_CONFLICT", 0) / max(ld.get("SQ_LDS_IDX_ACTIVE", 0), 1),
             ic.get("SQC_ICACHE_MISSES", 0) / max(ic.get("SQC_ICACHE_REQ", 0), 1), ic.get("SQC_ICACHE_REQ", 0) / max(us, 1e-9)))
 print()
 for name, (us, f, w, c) in sorted(tot.items(), key=lambda x: -x[1][0]):
